@@ -1,0 +1,94 @@
+/* pnp_hip.h -- C ABI of the MI355X (gfx950) PnP-SVRG/SAGA/SARAH hot path.
+ *
+ * The reference (vmonardo/pnp-svrg @ v1) is pure Python: it has no FFI of its own.  Its
+ * boundary for this path is the duck-typed protocol of its algorithms/, problems/ and
+ * denoisers/ packages.  This header is the native side a maintainer binds with
+ * ctypes (INTEGRATION.md shows the stub); each entry point names the reference code it
+ * replaces.
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer (HBM); `stream` is a hipStream_t passed as void*;
+ *  - nothing here allocates, frees or synchronises inside a hot call: plans own their
+ *    workspaces (created/destroyed explicitly), so every call may be captured in a hipGraph;
+ *  - `dtype`: PNP_F32 (production) or PNP_F64 (parity/debug); complex = interleaved (re,im);
+ *  - images are row-major [B][H][W]; B independent problems ("batch") per call;
+ *  - return 0 on success, nonzero on error; text via pnp_last_error() (thread-local).
+ */
+#ifndef PNP_HIP_H
+#define PNP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PNP_F32 = 0, PNP_F64 = 1 };
+enum { PNP_OK = 0, PNP_ERR_ARG = 1, PNP_ERR_HIP = 2, PNP_ERR_UNSUPPORTED = 3 };
+
+int pnp_version(void);
+const char* pnp_last_error(void);
+
+/* ------------------------------------------------------------------ CSMRI masked FFT
+ * Replaces problems/CSMRI.py:76-81 (grad_full) and :83-89 (grad_stoch), i.e.
+ *   g = Re ifft2( sel o fft2(a - b) - sel o Y )
+ * computed with real FFTs on the Hermitian-symmetrised k-space residual.            */
+typedef struct pnp_csmri_plan pnp_csmri_plan;
+
+/* H == W in {64, 256}.  The plan owns a [batch][W/2][H] complex workspace + twiddles. */
+int pnp_csmri_plan_create(pnp_csmri_plan** plan, int H, int W, int batch, int dtype);
+int pnp_csmri_plan_destroy(pnp_csmri_plan* plan);
+
+/* Selector (sampling mask, or mask o minibatch) from flat row-major k-space indices, as
+ * np.flatnonzero(mask) / problems/CSMRI.py:66-74 produce them.  idx: [batch][n] int32,
+ * selT: [batch][W][H] uint8 (TRANSPOSED: the column pass reads along ky).              */
+int pnp_csmri_sel_from_indices(pnp_csmri_plan* plan, const int32_t* idx, int n, uint8_t* selT, void* stream);
+/* Same, from a dense row-major 0/1 indicator [batch][H][W] (uint8).                      */
+int pnp_csmri_sel_from_dense(pnp_csmri_plan* plan, const uint8_t* sel, uint8_t* selT, void* stream);
+
+/* Data term for a selector: yh = Hermitian part of (sel o Y) in the packed transposed
+ * half-spectrum layout [batch][W/2][H] complex (column 0 carries kx=0 and kx=W/2).
+ * YT: [batch][W][H] complex = Y transposed (measurements, CSMRI.py:32-33).               */
+int pnp_csmri_pack_y(pnp_csmri_plan* plan, const void* YT, const uint8_t* selT, void* yh, void* stream);
+
+/* out = alpha * Re ifft2( sel o fft2(a - b) - sel o Y ) + beta * c1 + gamma * c2
+ *   b, yh, c1, c2 may be NULL (treated as zero).  out may alias a, c1 or c2.
+ *   grad_full(z)            : a=z, sel=mask,   yh=pack(mask),    alpha=1/M0
+ *   SVRG correction + step  : a=z, b=w, sel=mask o mb, yh=NULL, alpha=-lr/mb, beta=1 (c1=z),
+ *                             gamma=-lr (c2=mu), out=z       (pnp_svrg.py:53,57) */
+int pnp_csmri_grad(pnp_csmri_plan* plan, const void* a, const void* b, const uint8_t* selT,
+                   const void* yh, double alpha, double beta, const void* c1,
+                   double gamma, const void* c2, void* out, void* stream);
+
+/* ------------------------------------------------------------------ prox / noise estimate
+ * estimate_sigma(z0, multichannel=True, average_sigmas=True) (algorithms/pnp_svrg.py:71):
+ * per-column db2 MAD, mean over columns.  sigma_out: [batch] (dtype).                    */
+int pnp_sigma_est(const void* z, int H, int W, int batch, int dtype, void* sigma_out, void* stream);
+
+/* TVDenoiser.denoise (denoisers/TV.py:21-26 = per-column Haar BayesShrink) fused with the
+ * noise estimate that feeds it and with the squared-error sum of Problem.PSNR
+ * (problems/problem.py:33-35).
+ *   sigma used = sigma_est*sigma_modifier if sigma_est > 0 else fallback_sigma
+ *   sigma_est  = sigma_in[b] if sigma_in != NULL else estimated in-kernel
+ *   xrec, sse_out may be NULL; sse_out: [batch] double = sum (xrec - out)^2
+ *   sigma_out (may be NULL): [batch] (dtype) the sigma_est that was used.               */
+int pnp_prox_tv(const void* z_in, void* z_out, int H, int W, int batch, int dtype,
+                const void* sigma_in, double sigma_modifier, double fallback_sigma,
+                const void* xrec, double* sse_out, void* sigma_out, void* stream);
+
+/* sum (xrec - z)^2 per problem (Problem.PSNR, problems/problem.py:33-35). sse_out: [batch] double */
+int pnp_sse(const void* z, const void* xrec, int n_per_problem, int batch, int dtype, double* sse_out, void* stream);
+
+/* per-problem min and max (RealSN_DnCNN.py:20-22). out: [batch][2] (dtype)               */
+int pnp_minmax(const void* z, int n_per_problem, int batch, int dtype, void* out, void* stream);
+
+/* ------------------------------------------------------------------ elementwise
+ * out = a*x + b*y + c*w   (y, w may be NULL); n = total element count.
+ * Covers z -= lr*v (pnp_gd.py:35), SAGA/SARAH combines (pnp_saga.py:47, pnp_sarah.py:72). */
+int pnp_axpbypcz(double a, const void* x, double b, const void* y, double c, const void* w,
+                 void* out, size_t n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNP_HIP_H */

@@ -1,0 +1,66 @@
+"""ctypes binding of the C-ABI library (include/pnp_hip.h -> pnp_svrg_amd/lib/libpnp_hip.so).
+
+There is no CPU fallback: if the library is missing or a call fails this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpnp_hip.so')
+
+F32, F64 = 0, 1
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_d = ctypes.c_double
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/pnp_hip.h declares
+SIGNATURES = {
+    'pnp_version': (_i, []),
+    'pnp_last_error': (ctypes.c_char_p, []),
+    'pnp_csmri_plan_create': (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i]),
+    'pnp_csmri_plan_destroy': (_i, [_vp]),
+    'pnp_csmri_sel_from_indices': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'pnp_csmri_sel_from_dense': (_i, [_vp, _vp, _vp, _vp]),
+    'pnp_csmri_pack_y': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'pnp_csmri_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _d, _vp, _vp, _vp]),
+    'pnp_sigma_est': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'pnp_prox_tv': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _d, _d, _vp, _vp, _vp, _vp]),
+    'pnp_sse': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'pnp_minmax': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'pnp_axpbypcz': (_i, [_d, _vp, _d, _vp, _d, _vp, _vp, _sz, _i, _vp]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C pnp_svrg_amd/csrc`). There is no CPU fallback.')
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(status, what=''):
+    if status != 0:
+        msg = lib().pnp_last_error().decode(errors='replace')
+        raise NativeError(f'{what} failed (status {status}): {msg}')
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,341 @@
+// csmri.hip -- masked-FFT data-fidelity gradient for CSMRI on gfx950.
+//
+// Replaces reference problems/CSMRI.py:76-81 (grad_full) and :83-89 (grad_stoch):
+//     g = Re ifft2( sel o fft2(x) - sel o Y )
+// The real part of an inverse FFT only sees the Hermitian part of its argument, so the
+// whole thing runs on the half spectrum with real<->complex transforms:
+//
+//   k_rows_fwd   two real image rows -> one complex FFT-W -> split -> packed half spectrum,
+//                written TRANSPOSED ([kx][h]) through an LDS tile (256-B segments)
+//   k_cols       per kx column: FFT-H -> symmetrised selector (and data term) -> inverse FFT-H,
+//                in one kernel, in place (forward and inverse share the axis)
+//   k_rows_inv   transposed read -> Hermitian re-expansion -> one complex inverse FFT-W gives two
+//                real rows -> fused epilogue  out = alpha*g + beta*c1 + gamma*c2
+//
+// "Packed": column kx=0 stores (X[.,0], X[.,W/2]) as (re,im) -- both are real after the row
+// pass -- so the half spectrum is exactly [W/2][H] complex = the bytes of the real image.
+#include "fft.h"
+#include <vector>
+#include <cmath>
+
+namespace pnp {
+
+template <typename T> struct alignas(4 * sizeof(T)) vec4 { T a, b, c, d; };
+
+template <typename T, int NL> struct FftSmem {
+    static constexpr int N = NL * NL;
+    static constexpr int G = 256 / NL;                       // lane groups per 256-thread block
+    static constexpr int TILE = G * (N + 1);                 // [group][N+1] complex
+    static constexpr int SCR = G * NL * (NL + 1);            // [group][NL][NL+1] complex
+    static constexpr int ELEMS = TILE > SCR ? TILE : SCR;
+};
+
+// ------------------------------------------------------------------------------- rows forward
+template <typename T, int NL>
+__global__ __launch_bounds__(256) void k_rows_fwd(const T* __restrict__ a, const T* __restrict__ b,
+                                                  cx<T>* __restrict__ S1T, const cx<T>* __restrict__ twtab, int H) {
+    using S = FftSmem<T, NL>;
+    constexpr int N = S::N, G = S::G;
+    __shared__ cx<T> smem[S::ELEMS];
+    const int t = threadIdx.x, g = t / NL, lane = t % NL;
+    const int prob = blockIdx.y, h0 = blockIdx.x * 2 * G;
+    const size_t img = (size_t)prob * H * N;
+    const size_t ra = img + (size_t)(h0 + 2 * g) * N, rb = ra + N;
+
+    cx<T> v[NL], tw[NL];
+    load_twiddles<T, NL>(tw, twtab, lane);
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        const int w = lane + NL * r;
+        T va = a[ra + w], vb = a[rb + w];
+        if (b != nullptr) { va -= b[ra + w]; vb -= b[rb + w]; }
+        v[r] = {va, vb};
+    }
+    fft_group<T, NL, false>(v, tw, smem + g * NL * (NL + 1), lane);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NL; ++r) smem[g * (N + 1) + lane + NL * r] = v[r];
+    __syncthreads();
+
+    // split the two interleaved real transforms and store transposed
+    const int p = t % G;
+    const cx<T>* zp = smem + p * (N + 1);
+    for (int kx = t / G; kx < N / 2; kx += 256 / G) {
+        const cx<T> zk = zp[kx], zm = zp[(N - kx) & (N - 1)];
+        vec4<T> o;
+        if (kx == 0) {
+            const cx<T> zn = zp[N / 2];
+            o = {zk.x, zn.x, zk.y, zn.y};
+        } else {
+            o = {(T)0.5 * (zk.x + zm.x), (T)0.5 * (zk.y - zm.y), (T)0.5 * (zk.y + zm.y), (T)-0.5 * (zk.x - zm.x)};
+        }
+        *reinterpret_cast<vec4<T>*>(S1T + ((size_t)prob * (N / 2) + kx) * H + h0 + 2 * p) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------- columns
+template <typename T, int NL>
+__global__ __launch_bounds__(256) void k_cols(cx<T>* __restrict__ S1T, const uint8_t* __restrict__ selT,
+                                              const cx<T>* __restrict__ yh, const cx<T>* __restrict__ twtab, int W) {
+    using S = FftSmem<T, NL>;
+    constexpr int N = S::N, G = S::G;                        // N = H
+    __shared__ cx<T> smem[S::SCR];
+    const int t = threadIdx.x, g = t / NL, lane = t % NL;
+    const int prob = blockIdx.y, c = blockIdx.x * G + g;
+    cx<T>* col = S1T + ((size_t)prob * (W / 2) + c) * N;
+    cx<T>* scr = smem + g * NL * (NL + 1);
+
+    cx<T> v[NL], tw[NL];
+    load_twiddles<T, NL>(tw, twtab, lane);
+#pragma unroll
+    for (int r = 0; r < NL; ++r) v[r] = col[lane + NL * r];
+    fft_group<T, NL, false>(v, tw, scr, lane);
+
+    const uint8_t* sp = selT + (size_t)prob * W * N;
+    if (blockIdx.x == 0) {
+        // the packed column c == 0 holds two real-input transforms: separate, weight, re-pack
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NL; ++r) scr[lane + NL * r] = v[r];
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int r = 0; r < NL; ++r) {
+                const int ky = lane + NL * r, km = (N - ky) & (N - 1);
+                const cx<T> pk = v[r], pm = scr[km];
+                const cx<T> A = {(T)0.5 * (pk.x + pm.x), (T)0.5 * (pk.y - pm.y)};
+                const cx<T> B = {(T)0.5 * (pk.y + pm.y), (T)-0.5 * (pk.x - pm.x)};
+                const T wA = (T)0.5 * (T)(sp[ky] + sp[km]);
+                const T wB = (T)0.5 * (T)(sp[(size_t)(W / 2) * N + ky] + sp[(size_t)(W / 2) * N + km]);
+                v[r] = {wA * A.x - wB * B.y, wA * A.y + wB * B.x};
+            }
+        }
+    }
+    if (c != 0) {
+        const uint8_t* s1 = sp + (size_t)c * N;
+        const uint8_t* s2 = sp + (size_t)(W - c) * N;
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+            const int ky = lane + NL * r, km = (N - ky) & (N - 1);
+            const T wgt = (T)0.5 * (T)(s1[ky] + s2[km]);
+            v[r] = {wgt * v[r].x, wgt * v[r].y};
+        }
+    }
+    if (yh != nullptr) {
+        const cx<T>* yc = yh + ((size_t)prob * (W / 2) + c) * N;
+#pragma unroll
+        for (int r = 0; r < NL; ++r) v[r] = csub(v[r], yc[lane + NL * r]);
+    }
+    fft_group<T, NL, true>(v, tw, scr, lane);
+#pragma unroll
+    for (int r = 0; r < NL; ++r) col[lane + NL * r] = v[r];
+}
+
+// ------------------------------------------------------------------------------- rows inverse + epilogue
+template <typename T, int NL>
+__global__ __launch_bounds__(256) void k_rows_inv(const cx<T>* __restrict__ S1T, const cx<T>* __restrict__ twtab, int H,
+                                                  T alpha, T beta, const T* c1, T gamma, const T* c2, T* out) {
+    using S = FftSmem<T, NL>;
+    constexpr int N = S::N, G = S::G;
+    __shared__ cx<T> smem[S::ELEMS];
+    const int t = threadIdx.x, g = t / NL, lane = t % NL;
+    const int prob = blockIdx.y, h0 = blockIdx.x * 2 * G;
+
+    const int p = t % G;
+    cx<T>* zp = smem + p * (N + 1);
+    for (int kx = t / G; kx < N / 2; kx += 256 / G) {
+        const vec4<T> q = *reinterpret_cast<const vec4<T>*>(S1T + ((size_t)prob * (N / 2) + kx) * H + h0 + 2 * p);
+        if (kx == 0) {
+            zp[0] = {q.a, q.c};
+            zp[N / 2] = {q.b, q.d};
+        } else {
+            zp[kx] = {q.a - q.d, q.b + q.c};                 // A + iB
+            zp[N - kx] = {q.a + q.d, q.c - q.b};             // conj(A) + i conj(B)
+        }
+    }
+    __syncthreads();
+    cx<T> v[NL], tw[NL];
+    load_twiddles<T, NL>(tw, twtab, lane);
+#pragma unroll
+    for (int r = 0; r < NL; ++r) v[r] = smem[g * (N + 1) + lane + NL * r];
+    fft_group<T, NL, true>(v, tw, smem + g * NL * (NL + 1), lane);
+
+    const size_t ra = (size_t)prob * H * N + (size_t)(h0 + 2 * g) * N, rb = ra + N;
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        const int w = lane + NL * r;
+        T oa = alpha * v[r].x, ob = alpha * v[r].y;
+        if (c1 != nullptr) { oa += beta * c1[ra + w]; ob += beta * c1[rb + w]; }
+        if (c2 != nullptr) { oa += gamma * c2[ra + w]; ob += gamma * c2[rb + w]; }
+        out[ra + w] = oa;
+        out[rb + w] = ob;
+    }
+}
+
+// ------------------------------------------------------------------------------- data term
+template <typename T>
+__global__ void k_pack_y(const cx<T>* __restrict__ YT, const uint8_t* __restrict__ selT, cx<T>* __restrict__ yh, int H, int W) {
+    const int prob = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (W / 2) * H) return;
+    const int c = i / H, ky = i % H;
+    const cx<T>* Y = YT + (size_t)prob * W * H;
+    const uint8_t* S = selT + (size_t)prob * W * H;
+    auto term = [&](int cc) -> cx<T> {
+        const size_t i1 = (size_t)cc * H + ky, i2 = (size_t)((W - cc) % W) * H + ((H - ky) % H);
+        const T s1 = (T)S[i1], s2 = (T)S[i2];
+        const cx<T> y1 = Y[i1], y2 = Y[i2];
+        return {(T)0.5 * (s1 * y1.x + s2 * y2.x), (T)0.5 * (s1 * y1.y - s2 * y2.y)};
+    };
+    cx<T> o;
+    if (c == 0) {
+        const cx<T> A = term(0), B = term(W / 2);
+        o = {A.x - B.y, A.y + B.x};
+    } else {
+        o = term(c);
+    }
+    yh[(size_t)prob * (W / 2) * H + i] = o;
+}
+
+__global__ void k_sel_scatter(const int32_t* __restrict__ idx, int n, uint8_t* __restrict__ selT, int H, int W) {
+    const int prob = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int i = idx[(size_t)prob * n + j];
+    if (i < 0 || i >= H * W) return;
+    selT[(size_t)prob * H * W + (size_t)(i % W) * H + i / W] = 1;
+}
+
+__global__ void k_sel_transpose(const uint8_t* __restrict__ sel, uint8_t* __restrict__ selT, int H, int W) {
+    __shared__ uint8_t tile[32][33];
+    const int prob = blockIdx.z;
+    const uint8_t* s = sel + (size_t)prob * H * W;
+    uint8_t* d = selT + (size_t)prob * H * W;
+    int x = blockIdx.x * 32 + threadIdx.x, y = blockIdx.y * 32 + threadIdx.y;
+    for (int j = 0; j < 32; j += 8)
+        if (x < W && y + j < H) tile[threadIdx.y + j][threadIdx.x] = s[(size_t)(y + j) * W + x] != 0;
+    __syncthreads();
+    x = blockIdx.y * 32 + threadIdx.x;
+    y = blockIdx.x * 32 + threadIdx.y;
+    for (int j = 0; j < 32; j += 8)
+        if (x < H && y + j < W) d[(size_t)(y + j) * H + x] = tile[threadIdx.x][threadIdx.y + j];
+}
+
+template <typename T> void fill_twiddles(std::vector<cx<T>>& tab, int N) {
+    tab.resize(N);
+    for (int j = 0; j < N; ++j) {
+        const double ang = -2.0 * 3.14159265358979323846 * j / N;
+        tab[j] = {(T)cos(ang), (T)sin(ang)};
+    }
+}
+
+}  // namespace pnp
+
+using namespace pnp;
+
+struct pnp_csmri_plan {
+    int H, W, batch, dtype, NL;
+    void* work;     // [batch][W/2][H] complex
+    void* twtab;    // [N] complex
+};
+
+extern "C" int pnp_csmri_plan_create(pnp_csmri_plan** out, int H, int W, int batch, int dtype) {
+    PNP_CHECK_ARG(out != nullptr, "null plan pointer");
+    PNP_CHECK_ARG(H == W && (H == 64 || H == 256), "supported sizes: H == W in {64, 256}");
+    PNP_CHECK_ARG(batch >= 1, "batch must be >= 1");
+    PNP_CHECK_ARG(dtype == PNP_F32 || dtype == PNP_F64, "dtype must be PNP_F32 or PNP_F64");
+    auto* p = new pnp_csmri_plan{H, W, batch, dtype, H == 256 ? 16 : 8, nullptr, nullptr};
+    const size_t esz = dtype == PNP_F32 ? 8 : 16;
+    hipError_t e = hipMalloc(&p->work, (size_t)batch * (W / 2) * H * esz);
+    if (e == hipSuccess) e = hipMalloc(&p->twtab, (size_t)H * esz);
+    if (e == hipSuccess) {
+        if (dtype == PNP_F32) {
+            std::vector<cx<float>> tab; fill_twiddles(tab, H);
+            e = hipMemcpy(p->twtab, tab.data(), H * esz, hipMemcpyHostToDevice);
+        } else {
+            std::vector<cx<double>> tab; fill_twiddles(tab, H);
+            e = hipMemcpy(p->twtab, tab.data(), H * esz, hipMemcpyHostToDevice);
+        }
+    }
+    if (e != hipSuccess) {
+        set_error(std::string("pnp_csmri_plan_create: ") + hipGetErrorString(e));
+        if (p->work) (void)hipFree(p->work);
+        if (p->twtab) (void)hipFree(p->twtab);
+        delete p;
+        return PNP_ERR_HIP;
+    }
+    *out = p;
+    return PNP_OK;
+}
+
+extern "C" int pnp_csmri_plan_destroy(pnp_csmri_plan* p) {
+    if (p == nullptr) return PNP_OK;
+    (void)hipFree(p->work);
+    (void)hipFree(p->twtab);
+    delete p;
+    return PNP_OK;
+}
+
+extern "C" int pnp_csmri_sel_from_indices(pnp_csmri_plan* p, const int32_t* idx, int n, uint8_t* selT, void* stream) {
+    PNP_CHECK_ARG(p && idx && selT && n >= 0, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    PNP_CHECK_HIP(hipMemsetAsync(selT, 0, (size_t)p->batch * p->H * p->W, s));
+    if (n > 0) {
+        k_sel_scatter<<<dim3((n + 255) / 256, p->batch), 256, 0, s>>>(idx, n, selT, p->H, p->W);
+        PNP_CHECK_LAUNCH();
+    }
+    return PNP_OK;
+}
+
+extern "C" int pnp_csmri_sel_from_dense(pnp_csmri_plan* p, const uint8_t* sel, uint8_t* selT, void* stream) {
+    PNP_CHECK_ARG(p && sel && selT, "null argument");
+    k_sel_transpose<<<dim3((p->W + 31) / 32, (p->H + 31) / 32, p->batch), dim3(32, 8), 0, (hipStream_t)stream>>>(
+        sel, selT, p->H, p->W);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+
+extern "C" int pnp_csmri_pack_y(pnp_csmri_plan* p, const void* YT, const uint8_t* selT, void* yh, void* stream) {
+    PNP_CHECK_ARG(p && YT && selT && yh, "null argument");
+    const int n = (p->W / 2) * p->H;
+    dim3 grid((n + 255) / 256, p->batch);
+    if (p->dtype == PNP_F32)
+        k_pack_y<float><<<grid, 256, 0, (hipStream_t)stream>>>((const cx<float>*)YT, selT, (cx<float>*)yh, p->H, p->W);
+    else
+        k_pack_y<double><<<grid, 256, 0, (hipStream_t)stream>>>((const cx<double>*)YT, selT, (cx<double>*)yh, p->H, p->W);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+
+namespace {
+template <typename T, int NL>
+int run_grad(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const void* yh, double alpha,
+             double beta, const void* c1, double gamma, const void* c2, void* out, hipStream_t s) {
+    constexpr int G = 256 / NL;
+    const int H = p->H, W = p->W;
+    cx<T>* work = (cx<T>*)p->work;
+    const cx<T>* tw = (const cx<T>*)p->twtab;
+    const T scale = (T)(alpha / ((double)H * (double)W));
+    k_rows_fwd<T, NL><<<dim3(H / (2 * G), p->batch), 256, 0, s>>>((const T*)a, (const T*)b, work, tw, H);
+    PNP_CHECK_LAUNCH();
+    k_cols<T, NL><<<dim3((W / 2) / G, p->batch), 256, 0, s>>>(work, selT, (const cx<T>*)yh, tw, W);
+    PNP_CHECK_LAUNCH();
+    k_rows_inv<T, NL><<<dim3(H / (2 * G), p->batch), 256, 0, s>>>(work, tw, H, scale, (T)beta, (const T*)c1, (T)gamma,
+                                                                 (const T*)c2, (T*)out);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+}  // namespace
+
+extern "C" int pnp_csmri_grad(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const void* yh,
+                              double alpha, double beta, const void* c1, double gamma, const void* c2, void* out,
+                              void* stream) {
+    PNP_CHECK_ARG(p && a && selT && out, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (p->dtype == PNP_F32) {
+        if (p->NL == 16) return run_grad<float, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+        return run_grad<float, 8>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+    }
+    if (p->NL == 16) return run_grad<double, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+    return run_grad<double, 8>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+}

@@ -1,0 +1,119 @@
+"""Torch-tensor front end of the C-ABI calls.  PyTorch is plumbing here: it owns HBM
+allocations and the HIP stream; every op below is one call into libpnp_hip.so."""
+import ctypes
+import torch
+from . import _native as N
+
+_DT = {torch.float32: N.F32, torch.float64: N.F64}
+_CDT = {torch.float32: torch.complex64, torch.float64: torch.complex128}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'device-resident contiguous tensors only'
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise N.NativeError('no MI355X visible (torch.cuda.is_available() is False); the hot path has no CPU fallback')
+    N.lib()
+
+
+class CsmriPlan:
+    """pnp_csmri_plan_* : masked-FFT gradient of B independent H x W CSMRI problems."""
+
+    def __init__(self, H, W, batch, dtype=torch.float32):
+        require_gpu()
+        self.H, self.W, self.B, self.dtype = H, W, batch, dtype
+        h = ctypes.c_void_p()
+        N.call('pnp_csmri_plan_create', ctypes.byref(h), H, W, batch, _DT[dtype])
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                N.lib().pnp_csmri_plan_destroy(h)
+            except Exception:
+                pass
+
+    def sel_from_indices(self, idx, out=None):
+        """idx: int32 [B, n] flat row-major k-space positions -> uint8 [B, W, H] (transposed)."""
+        assert idx.dtype == torch.int32 and idx.shape[0] == self.B
+        out = out if out is not None else torch.empty((self.B, self.W, self.H), dtype=torch.uint8, device=idx.device)
+        N.call('pnp_csmri_sel_from_indices', self._h, _p(idx), idx.shape[1], _p(out), _stream())
+        return out
+
+    def sel_from_dense(self, sel, out=None):
+        assert sel.dtype == torch.uint8 and tuple(sel.shape) == (self.B, self.H, self.W)
+        out = out if out is not None else torch.empty((self.B, self.W, self.H), dtype=torch.uint8, device=sel.device)
+        N.call('pnp_csmri_sel_from_dense', self._h, _p(sel), _p(out), _stream())
+        return out
+
+    def pack_y(self, YT, selT, out=None):
+        """YT: complex [B, W, H] (Y transposed); returns packed data term complex [B, W/2, H]."""
+        assert YT.dtype == _CDT[self.dtype] and tuple(YT.shape) == (self.B, self.W, self.H)
+        out = out if out is not None else torch.empty((self.B, self.W // 2, self.H), dtype=YT.dtype, device=YT.device)
+        N.call('pnp_csmri_pack_y', self._h, _p(YT), _p(selT), _p(out), _stream())
+        return out
+
+    def grad(self, a, selT, b=None, yh=None, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None):
+        """out = alpha * Re ifft2(sel o fft2(a - b) - sel o Y) + beta*c1 + gamma*c2."""
+        for t in (a, b, c1, c2, out):
+            assert t is None or (t.dtype == self.dtype and t.numel() == self.B * self.H * self.W)
+        out = out if out is not None else torch.empty_like(a)
+        N.call('pnp_csmri_grad', self._h, _p(a), _p(b), _p(selT), _p(yh), float(alpha), float(beta), _p(c1),
+               float(gamma), _p(c2), _p(out), _stream())
+        return out
+
+
+def sigma_est(z):
+    """z: [B, H, W] -> [B] (estimate_sigma(multichannel=True, average_sigmas=True))."""
+    require_gpu()
+    B, H, W = z.shape
+    out = torch.empty(B, dtype=z.dtype, device=z.device)
+    N.call('pnp_sigma_est', _p(z), H, W, B, _DT[z.dtype], _p(out), _stream())
+    return out
+
+
+def prox_tv(z, sigma_in=None, sigma_modifier=1.0, fallback_sigma=0.0, xrec=None, out=None, sse=None, sigma_out=None):
+    """Fused estimate_sigma + Haar-BayesShrink prox (+ squared error vs xrec).
+    Returns (denoised [B,H,W], sse [B] float64 or None, sigma_est [B])."""
+    require_gpu()
+    B, H, W = z.shape
+    out = out if out is not None else torch.empty_like(z)
+    if xrec is not None and sse is None:
+        sse = torch.empty(B, dtype=torch.float64, device=z.device)
+    sigma_out = sigma_out if sigma_out is not None else torch.empty(B, dtype=z.dtype, device=z.device)
+    N.call('pnp_prox_tv', _p(z), _p(out), H, W, B, _DT[z.dtype], _p(sigma_in), float(sigma_modifier),
+           float(fallback_sigma), _p(xrec), _p(sse), _p(sigma_out), _stream())
+    return out, sse, sigma_out
+
+
+def sse(z, xrec, out=None):
+    require_gpu()
+    B = z.shape[0]
+    out = out if out is not None else torch.empty(B, dtype=torch.float64, device=z.device)
+    N.call('pnp_sse', _p(z), _p(xrec), z.numel() // B, B, _DT[z.dtype], _p(out), _stream())
+    return out
+
+
+def minmax(z):
+    require_gpu()
+    B = z.shape[0]
+    out = torch.empty((B, 2), dtype=z.dtype, device=z.device)
+    N.call('pnp_minmax', _p(z), z.numel() // B, B, _DT[z.dtype], _p(out), _stream())
+    return out
+
+
+def axpbypcz(a, x, b=0.0, y=None, c=0.0, w=None, out=None):
+    require_gpu()
+    out = out if out is not None else torch.empty_like(x)
+    N.call('pnp_axpbypcz', float(a), _p(x), float(b), _p(y), float(c), _p(w), _p(out), x.numel(), _DT[x.dtype], _stream())
+    return out

@@ -1,0 +1,211 @@
+"""Host-side mirror of the reference's `problems/*` interface, backed by the HIP kernels.
+
+Same names, constructor arguments, attributes, return conventions and error behaviour as
+reference problems/problem.py, problems/CSMRI.py; the data-fidelity gradients
+run on the MI355X through the C ABI.  Problem *construction* (image load, random mask /
+noise from the global legacy `np.random` stream, forward model) is one-off setup and stays
+in NumPy float64 so that a seed reproduces the reference's data bit for bit.
+
+Extensions (keyword-only, all optional): `img=` (pixel array instead of a path),
+`dtype=` (torch.float32 production / torch.float64 parity), `device=`.
+Gradient methods accept either a NumPy vector (returns NumPy float64, like the reference)
+or a device tensor (returns a device tensor: the loops use this form and never leave HBM).
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+_DEFAULT_DTYPE = torch.float32
+
+
+def set_default_dtype(dtype):
+    """torch.float32 (production) or torch.float64 (parity/debug) for newly built problems."""
+    global _DEFAULT_DTYPE
+    assert dtype in (torch.float32, torch.float64)
+    _DEFAULT_DTYPE = dtype
+
+
+def get_default_dtype():
+    return _DEFAULT_DTYPE
+
+
+class Problem():
+    """reference problems/problem.py:8-129."""
+
+    def __init__(self, img_path, H, W, *, img=None, dtype=None, device='cuda:0'):
+        self.H = H
+        self.W = W
+        self.N = H * W
+        self.M = self.N
+        if img is not None:
+            tmp = np.asarray(img)
+        elif img_path is not None:
+            from PIL import Image
+            tmp = np.array(Image.open(img_path).resize((H, W)))
+        else:
+            raise Exception('Need to pass in image path or image')
+        tmp = (tmp - np.min(tmp)) / (np.max(tmp) - np.min(tmp))
+        self.Xrec = tmp
+        self.X = tmp.ravel()
+        self.Xinit = np.empty_like(self.X)
+        # device side
+        ops.require_gpu()
+        self.dtype = dtype if dtype is not None else _DEFAULT_DTYPE
+        self.device = torch.device(device)
+        self._xrec_d = self.to_device(self.Xrec).reshape(1, H, W)
+
+    # ---- host <-> device helpers (extensions)
+    def to_device(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=self.dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device=self.device, dtype=self.dtype)
+
+    @staticmethod
+    def _is_dev(a):
+        return isinstance(a, torch.Tensor)
+
+    def _ret(self, t, like):
+        return t if self._is_dev(like) else t.reshape(-1).double().cpu().numpy()
+
+    def get_item(self, key):
+        return self.__dict__[key]
+
+    def sse_device(self, w_dev):
+        """sum (Xrec - w)^2 on the device; float64 scalar tensor [1]."""
+        return ops.sse(w_dev.reshape(1, self.H, self.W), self._xrec_d)
+
+    @staticmethod
+    def psnr_from_sse(sse, n):
+        """reference problems/problem.py:33-35: 10 log10(1/mse), rounded to 2 decimals."""
+        with np.errstate(divide='ignore'):
+            return np.around(10 * np.log10(1.0 / (np.float64(sse) / n)), decimals=2)
+
+    def PSNR(self, w):
+        w_dev = w if self._is_dev(w) else self.to_device(w)
+        return self.psnr_from_sse(self.sse_device(w_dev).item(), self.N)
+
+    def set_snr_sigma(self):
+        if self.snr is not None and self.sigma is None:
+            self.sigma = self.get_sigma_from_snr()
+        elif self.sigma is not None and self.snr is None:
+            self.snr = self.get_snr_from_sigma()
+        elif self.snr is None and self.sigma is None:
+            self.sigma = 0
+            self.snr = 10e9
+        else:
+            raise Exception('Please specify either sigma (sigma) or signal-to-noise ratio (snr).')
+
+    def get_snr_from_sigma(self):
+        if self.sigma > 0:
+            return 10 * np.log10(np.linalg.norm(self.Y0.ravel()) / self.sigma ** 2 / self.H / self.W)
+        elif self.sigma == 0:
+            return 10e9
+        raise Exception('Sigma cannot be negative.')
+
+    def get_sigma_from_snr(self):
+        # the reference divides the NORM (not its square) by the linear SNR; kept as is
+        return np.sqrt(np.linalg.norm(self.Y0.ravel()) / 10 ** (self.snr / 10) / self.H / self.W)
+
+    def display(self, *args, **kwargs):
+        raise NotImplementedError('plotting is out of scope of the MI355X hot path (SURVEY section 2)')
+
+    def select_mb(self, size):
+        if size > self.M:
+            print('MB size is too big: ', size, ' > ', self.M)
+        batch = np.zeros(self.M)
+        batch_locs = np.random.choice(self.M, size, replace=False)
+        batch[batch_locs] = 1
+        return batch.astype(int)
+
+    def f(self, z):
+        raise NotImplementedError('Need to implement f() method')
+
+    def grad_full(self, z):
+        raise NotImplementedError('Need to implement full_grad() method')
+
+    def grad_stoch(self, z, mb_indices):
+        raise NotImplementedError('Need to implement stoch_grad() method')
+
+
+class CSMRI(Problem):
+    """reference problems/CSMRI.py:11-89 with the gradients on the MI355X."""
+
+    def __init__(self, img_path=None, H=256, W=256, sample_prob=0.5, snr=None, sigma=None, **ext):
+        super().__init__(img_path, H, W, **ext)
+        self.pname = 'csmri'
+        self.sample_prob = sample_prob
+        self.snr = snr
+        self.sigma = sigma
+
+        self._generate_mask()
+        self.Y0 = self.forward_model(self.X)
+        self.set_snr_sigma()
+        noises = np.random.normal(0, self.sigma, self.Y0.shape)
+        self.Y = self.Y0 + np.multiply(self.mask, noises)
+        self.SNR = self.get_snr_from_sigma
+        self.Xinit = np.absolute(np.fft.ifft2(self.Y)).ravel()
+        self.Xinit = (self.Xinit - np.min(self.Xinit)) / (np.max(self.Xinit) - np.min(self.Xinit))
+        self.lrH, self.lrW = self.H, self.W
+        self.M = self.N
+        self.M0 = np.count_nonzero(self.mask)
+        self._upload()
+
+    def _generate_mask(self):
+        self.mask = np.random.choice([0, 1], size=(self.H, self.W), p=[1 - self.sample_prob, self.sample_prob])
+
+    def forward_model(self, w):
+        # reference CSMRI.py:53-59 multiplies by a dense DFT matrix (== fft2 to 3e-11 for H == W)
+        return np.multiply(self.mask, np.fft.fft2(w.reshape(self.H, self.W)))
+
+    def f(self, w):
+        w = w.double().cpu().numpy() if self._is_dev(w) else w
+        return np.linalg.norm(self.Y - self.forward_model(w)) ** 2 / 2 / self.M
+
+    # ---- device state
+    def _upload(self):
+        H, W = self.H, self.W
+        cdt = torch.complex64 if self.dtype == torch.float32 else torch.complex128
+        self.plan = ops.CsmriPlan(H, W, 1, self.dtype)
+        self._mask_idx = np.flatnonzero(self.mask).astype(np.int32)
+        self._YT = torch.from_numpy(np.ascontiguousarray(self.Y.T)).to(self.device, cdt).reshape(1, W, H).contiguous()
+        idx = torch.from_numpy(self._mask_idx).to(self.device).reshape(1, -1)
+        self._maskT = self.plan.sel_from_indices(idx)
+        self._yh_full = self.plan.pack_y(self._YT, self._maskT)
+        self._selT = torch.empty_like(self._maskT)
+        self._yh = torch.empty_like(self._yh_full)
+
+    def select_mb(self, size):
+        if size > self.M:
+            print('MB size is too big: ', size, ' > ', self.M)
+        batch = np.zeros(self.M)
+        mask_locs = np.asarray(np.flatnonzero(self.mask))
+        batch_locs = np.random.choice(mask_locs, size, replace=False)
+        batch[batch_locs] = 1
+        return batch.reshape(self.H, self.W).astype(int)
+
+    def _selector(self, mb):
+        """mask o mb (CSMRI.py:84) -> transposed device selector."""
+        sel = np.flatnonzero(np.multiply(self.mask, np.asarray(mb).reshape(self.H, self.W))).astype(np.int32)
+        idx = torch.from_numpy(sel).to(self.device).reshape(1, -1)
+        return self.plan.sel_from_indices(idx, out=self._selT)
+
+    def grad_full(self, z):
+        zd = (z if self._is_dev(z) else self.to_device(z)).reshape(1, self.H, self.W)
+        g = self.plan.grad(zd, self._maskT, yh=self._yh_full, alpha=1.0 / self.M0)
+        return self._ret(g.reshape(-1), z)
+
+    def grad_stoch(self, z, mb, *, scale=1.0):
+        zd = (z if self._is_dev(z) else self.to_device(z)).reshape(1, self.H, self.W)
+        selT = self._selector(mb)
+        yh = self.plan.pack_y(self._YT, selT, out=self._yh)
+        g = self.plan.grad(zd, selT, yh=yh, alpha=scale)
+        return self._ret(g.reshape(-1), z)
+
+    def grad_stoch_diff(self, z, w, mb, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None):
+        """alpha*(grad_stoch(z,mb) - grad_stoch(w,mb)) + beta*c1 + gamma*c2 in ONE FFT pair
+        (the Y terms cancel).  Device tensors only."""
+        shp = (1, self.H, self.W)
+        selT = self._selector(mb)
+        return self.plan.grad(z.reshape(shp), selT, b=w.reshape(shp), alpha=alpha, beta=beta, c1=c1,
+                              gamma=gamma, c2=c2, out=out)

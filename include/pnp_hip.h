@@ -82,6 +82,26 @@ int pnp_sse(const void* z, const void* xrec, int n_per_problem, int batch, int d
 /* per-problem min and max (RealSN_DnCNN.py:20-22). out: [batch][2] (dtype)               */
 int pnp_minmax(const void* z, int n_per_problem, int batch, int dtype, void* out, void* stream);
 
+/* ------------------------------------------------------------------ DnCNN prox (MFMA)
+ * Replaces RealSN_DnCNNDenoiser.denoise (denoisers/RealSN_DnCNN.py:16-42) around the 17-layer
+ * network of denoisers/DeepDenoisers/model/models.py:5-22 (realSN_models.py:4-21 at inference:
+ * the spectral-norm hook only detaches the stored weight).
+ * Weights are HOST pointers (plan creation is setup): BatchNorm already folded by the caller.
+ *   w_first [64][3][3]            conv(1->64), no bias
+ *   w_mid   [n_mid][64][64][3][3] conv(64->64) x BN scale;  b_mid [n_mid][64] folded BN bias
+ *   w_last  [64][3][3]            conv(64->1), no bias
+ * H % 8 == 0, W % 32 == 0.  The plan owns two [batch][64][H][W] fp32 activation buffers.   */
+typedef struct pnp_dncnn_plan pnp_dncnn_plan;
+int pnp_dncnn_plan_create(pnp_dncnn_plan** plan, int n_mid, const float* w_first, const float* w_mid,
+                          const float* b_mid, const float* w_last, int H, int W, int batch);
+int pnp_dncnn_plan_destroy(pnp_dncnn_plan* plan);
+/* raw network: r = net(x), x and r [batch][H][W] fp32 (the predicted noise residual)          */
+int pnp_dncnn_forward(pnp_dncnn_plan* plan, const float* x, float* r, void* stream);
+/* the whole denoise(): min-max normalise, scale by 1 + sigma_net/255/2, x - net(x), undo both;
+ * z_in/z_out/xrec in `dtype` (may alias); sse_out [batch] double = sum (xrec - z_out)^2 or NULL. */
+int pnp_dncnn_denoise(pnp_dncnn_plan* plan, const void* z_in, void* z_out, int dtype, double sigma_net,
+                      const void* xrec, double* sse_out, void* stream);
+
 /* ------------------------------------------------------------------ elementwise
  * out = a*x + b*y + c*w   (y, w may be NULL); n = total element count.
  * Covers z -= lr*v (pnp_gd.py:35), SAGA/SARAH combines (pnp_saga.py:47, pnp_sarah.py:72). */

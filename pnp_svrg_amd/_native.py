@@ -29,6 +29,10 @@ SIGNATURES = {
     'pnp_prox_tv': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _d, _d, _vp, _vp, _vp, _vp]),
     'pnp_sse': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'pnp_minmax': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'pnp_dncnn_plan_create': (_i, [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    'pnp_dncnn_plan_destroy': (_i, [_vp]),
+    'pnp_dncnn_forward': (_i, [_vp, _vp, _vp, _vp]),
+    'pnp_dncnn_denoise': (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     'pnp_axpbypcz': (_i, [_d, _vp, _d, _vp, _d, _vp, _vp, _sz, _i, _vp]),
 }
 

@@ -1,0 +1,398 @@
+// dncnn.hip -- DnCNN-17 prox (reference denoisers/RealSN_DnCNN.py:16-42 around the network of
+// denoisers/DeepDenoisers/model/models.py:5-22 / realSN_models.py:4-21) on gfx950.
+//
+//   k_first   1 -> 64 channels, 3x3, ReLU; fused with the min-max normalisation and the
+//             "1 + sigma/255/2" range scaling of the wrapper (RealSN_DnCNN.py:19-29)
+//   k_mid     64 -> 64 channels, 3x3, BatchNorm folded into weights + bias, ReLU:
+//             implicit GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, the
+//             reference network's own precision).  x15 per forward = 99.8 % of the FLOPs.
+//   k_last    64 -> 1 channel, 3x3; fused with x = xtilde - r, the inverse scaling and the squared
+//             error of Problem.PSNR (RealSN_DnCNN.py:36-40, problems/problem.py:33-35)
+//
+// k_mid design (one workgroup = 4 waves = one wave per SIMD, persistent over output tiles):
+//   * output tile: 8 rows x 32 columns x 64 channels.  D[cout][pixel] = sum_k W[cout][k] X[k][pixel]
+//     with K = 9 taps x 64 channels = 576: A operand = weights (rows = cout), B operand =
+//     activations (columns = 32 adjacent pixels of one row) so that every accumulator register
+//     holds 32 adjacent pixels of one channel -> 128-byte coalesced stores into NCHW.
+//   * WEIGHT-STATIONARY: wave (nh, mg) owns couts [32nh, 32nh+32) and rows [4mg, 4mg+4).  Its
+//     576 x 32 weight slice sits in 288 VGPRs for the life of the kernel (the unified 512-entry
+//     register file of gfx950 makes that possible at one wave per SIMD) -- weights are fetched from
+//     L2 once per launch, never per tile, and never go through LDS.
+//   * activations: the (8+2) x (32+2) halo tile of 32 input channels (one K-half) lives in LDS as
+//     channel planes [cin][10][34] -> the B operand of an MFMA is ONE conflict-free ds_read_b32
+//     (32 adjacent pixels per half-wave).  Two K-halves = two LDS buffers = a natural double buffer:
+//     while the MFMAs chew on one half, the next half (or the next tile's first half) is in flight
+//     global -> VGPR, and is written to the other buffer at the end of the phase.
+//   * per wave and phase: 576 MFMAs (64 cycles each) vs 576 ds_read_b32 + 43 global loads: the
+//     matrix pipe is the only busy resource by a wide margin.
+#include "common.h"
+#include <vector>
+
+namespace pnp {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int C = 64;             // feature channels
+constexpr int TR = 8, TC = 32;    // output tile rows / cols
+constexpr int PR = TR + 2, PC = TC + 2;
+constexpr int PLANE = PR * PC;    // 340 floats of halo tile per channel
+constexpr int PLANE_P = 368;      // padded plane stride: 368 % 32 == 16 -> the 4 k-rows of a B operand
+                                  // (lanes 0-15 / 16-31 of each half-wave) fall on disjoint LDS banks
+constexpr int HALF_C = 32;        // channels per K-half
+constexpr int HALF_ELEMS = HALF_C * PLANE;            // 10880 payload floats per half
+constexpr int HALF_LDS = HALF_C * PLANE_P;            // 11776 floats = 46 KB per LDS buffer
+
+constexpr int KSTEPS_HALF = 9 * (HALF_C / 4);         // 72 MFMA K-steps (K=4 each) per half
+constexpr int MT = 16;                                // 16-pixel M-tiles per output tile (8 rows x 2)
+
+// Stage one K-half of an input halo tile global (NCHW) -> LDS by LDS-DMA (global_load_lds): no
+// staging registers, no ds_write.  One wave-instruction writes 64 consecutive floats of the LDS
+// image; the SOURCE address is per lane (halo rows are 34 floats; image borders read a zero word).
+// LDS image: [cin][PLANE_P] with the first 340 floats of each plane = [10][34] halo tile, so a
+// 64-float piece may straddle two planes: the per-lane source handles that, the destination is
+// contiguous only within a plane -> pieces are cut per plane (6 pieces of 64 cover 340 -> 384 slots,
+// the 44 surplus slots land in the plane's padding / are never read).
+__device__ __forceinline__ void dma_half(const float* __restrict__ in, const float* __restrict__ zeros,
+                                         float* ldsbuf, int H, int W, int b, int ty0, int tx0, int half, int tid,
+                                         bool valid_tile) {
+    const int wv = tid >> 6, lane = tid & 63;
+    // 32 planes x 6 pieces = 192 pieces; wave wv takes pieces wv, wv+4, ...
+#pragma unroll 1
+    for (int pc = wv; pc < HALF_C * 6; pc += 4) {
+        const int cin = pc / 6, part = pc - cin * 6;
+        const int rem = part * 64 + lane;                       // position inside the plane
+        const float* src = zeros;
+        if (rem < PLANE) {
+            const int ry = rem / PC, rx = rem - ry * PC;
+            const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
+            if (valid_tile && y >= 0 && y < H && x >= 0 && x < W)
+                src = in + (((size_t)b * C + half * HALF_C + cin) * H + y) * W + x;
+        }
+        // last piece of a plane: 340 - 320 = 20 payload floats; slots 340..367 are padding, and
+        // slots 368..383 would spill into the next plane -> cut the piece to the padded stride
+        if (part < 5 || lane < PLANE_P - 320)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ldsbuf + cin * PLANE_P + part * 64), 4, 0, 0);
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, float* __restrict__ out,
+                                                const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                const float* __restrict__ zeros, int H, int W, int ntiles) {
+    __shared__ float lds[2 * HALF_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
+
+    // weight slice of this wave (16 couts x 576): wreg[s] = W'[16wv + (lane&15)][k = 4s + (lane>>4)]
+    float wreg[2 * KSTEPS_HALF];
+#pragma unroll
+    for (int s = 0; s < 2 * KSTEPS_HALF; ++s) wreg[s] = wpack[((size_t)wv * 2 * KSTEPS_HALF + s) * 64 + lane];
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[16 * wv + 4 * (lane >> 4) + r];
+
+    const int lbase = (lane >> 4) * PLANE_P + (lane & 15);     // lane part of the B-operand LDS address
+
+    int tile = blockIdx.x;
+    {
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        dma_half(in, zeros, lds, H, W, b, (t2 / tiles_x) * TR, (t2 % tiles_x) * TC, 0, tid, tile < ntiles);
+    }
+    __syncthreads();                                        // (drains the DMA: vmcnt(0) + barrier)
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // prefetch: the other K-half of this tile, or the first K-half of the next tile
+            float* nbuf = lds + (half ^ 1) * HALF_LDS;
+            if (half == 0) {
+                dma_half(in, zeros, nbuf, H, W, b, ty0, tx0, 1, tid, true);
+            } else {
+                const int nt = tile + gridDim.x;
+                const int nb = nt / tiles_per_img, n2 = nt - nb * tiles_per_img;
+                dma_half(in, zeros, nbuf, H, W, nb, (n2 / tiles_x) * TR, (n2 % tiles_x) * TC, 0, tid, nt < ntiles);
+            }
+            const float* xb = lds + half * HALF_LDS + lbase;
+#pragma unroll
+            for (int c4 = 0; c4 < HALF_C / 4; ++c4) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    // the 10 halo rows x 2 column halves of this (channel quad, dx): each value feeds
+                    // up to three taps (dy) -> 20 ds_read_b32 per 48 MFMAs
+                    float xr[PR][2];
+#pragma unroll
+                    for (int ry = 0; ry < PR; ++ry)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) xr[ry][h] = xb[(4 * c4) * PLANE_P + ry * PC + 16 * h + dx];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int s = half * KSTEPS_HALF + (dy * 3 + dx) * (HALF_C / 4) + c4;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], xr[(m >> 1) + dy][m & 1], acc[m], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();                                // next buffer landed (vmcnt(0)) + everyone done reading
+        }
+
+        // epilogue: bias (+ReLU); each accumulator register = 16 adjacent pixels of one channel
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int y = ty0 + (m >> 1), x = tx0 + 16 * (m & 1) + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cout = 16 * wv + 4 * (lane >> 4) + r;
+                float v = acc[m][r] + bv[r];
+                if (RELU) v = v > 0.f ? v : 0.f;
+                out[(((size_t)b * C + cout) * H + y) * W + x] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- first layer
+// xt = ((z - lo) / (hi - lo)) * srange + sshift ; act[c] = relu(sum_t w[c][t] * xt[tap t])
+template <typename T>
+__global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T* __restrict__ mm,
+                                               const float* __restrict__ w, float* __restrict__ out,
+                                               int H, int W, double srange, double sshift) {
+    __shared__ float ws[C * 9];
+    for (int i = threadIdx.x; i < C * 9; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const T lo = mm ? mm[2 * b] : (T)0, hi = mm ? mm[2 * b + 1] : (T)1;
+    const T* zi = z + (size_t)b * H * W;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        float q = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            T u = (zi[yy * W + xx] - lo) / (hi - lo);
+            u = u * (T)srange + (T)sshift;
+            q = (float)u;
+        }
+        v[t] = q;
+    }
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a = fmaf(ws[c * 9 + t], v[t], a);
+        out[((size_t)b * C + c) * H * W + p] = a > 0.f ? a : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------- last layer
+// r = sum_{c,t} w[c][t] * act[c][tap t];  x = xt - r;  x = (x - sshift)/srange;  z = x*(hi-lo)+lo
+template <typename T>
+__global__ __launch_bounds__(256) void k_last(const float* __restrict__ act, const float* __restrict__ w,
+                                              const T* __restrict__ zin, const T* __restrict__ mm,
+                                              T* zout, float* __restrict__ r_out,
+                                              const T* __restrict__ xrec, double* __restrict__ sse_part, int H, int W,
+                                              double srange, double sshift) {
+    __shared__ float ws[C * 9];
+    __shared__ double red[4];
+    for (int i = threadIdx.x; i < C * 9; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int y = p / W, x = p - y * W;
+    float r = 0.f;
+    const float* ab = act + (size_t)b * C * H * W;
+    for (int c = 0; c < C; ++c) {
+        const float* ac = ab + (size_t)c * H * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) r = fmaf(ws[c * 9 + t], ac[yy * W + xx], r);
+        }
+    }
+    double err = 0.0;
+    if (r_out != nullptr) r_out[(size_t)b * H * W + p] = r;
+    if (zout != nullptr) {
+        const T lo = mm[2 * b], hi = mm[2 * b + 1];
+        T v = (zin[(size_t)b * H * W + p] - lo) / (hi - lo);
+        v = v * (T)srange + (T)sshift;                      // xtilde, kept in T (f64 in the reference wrapper)
+        v = v - (T)r;                                       // f64 - f32 in the reference wrapper
+        v = (v - (T)sshift) / (T)srange;
+        v = v * (hi - lo) + lo;
+        zout[(size_t)b * H * W + p] = v;
+        if (xrec != nullptr) {
+            const double d = (double)xrec[(size_t)b * H * W + p] - (double)v;
+            err = d * d;
+        }
+    }
+    if (sse_part != nullptr) {
+        err = wave_sum(err);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = err;
+        __syncthreads();
+        if (threadIdx.x == 0) sse_part[(size_t)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+__global__ void k_sum_parts(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[(size_t)blockIdx.x * nparts + i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_minmax2(const T* __restrict__ z, int n, T* __restrict__ out) {
+    __shared__ T rmin[4], rmax[4];
+    const size_t base = (size_t)blockIdx.x * n;
+    T lo = z[base], hi = lo;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const T v = z[base + i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) { rmin[threadIdx.x >> 6] = lo; rmax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { lo = rmin[i] < lo ? rmin[i] : lo; hi = rmax[i] > hi ? rmax[i] : hi; }
+        out[2 * blockIdx.x] = lo;
+        out[2 * blockIdx.x + 1] = hi;
+    }
+}
+
+}  // namespace pnp
+
+using namespace pnp;
+
+struct pnp_dncnn_plan {
+    int n_mid, H, W, batch, num_cu;
+    float *w_first, *w_last, *wpack, *bias;      // device
+    float *act0, *act1, *zeros;                  // [B][64][H][W] x2; a zero word for halo padding
+    double* mm;                                  // [B][2] (as double or float depending on call)
+    double* sse_part;                            // [B][H*W/256]
+};
+
+extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const float* w_first, const float* w_mid,
+                                     const float* b_mid, const float* w_last, int H, int W, int batch) {
+    PNP_CHECK_ARG(out && w_first && w_mid && b_mid && w_last, "null argument");
+    PNP_CHECK_ARG(n_mid >= 1 && batch >= 1, "n_mid and batch must be >= 1");
+    PNP_CHECK_ARG(H % TR == 0 && W % TC == 0 && (H * W) % 256 == 0, "H must be a multiple of 8, W of 32");
+    auto* p = new pnp_dncnn_plan{};
+    p->n_mid = n_mid; p->H = H; p->W = W; p->batch = batch;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    PNP_CHECK_HIP(hipGetDevice(&dev));
+    PNP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    p->num_cu = prop.multiProcessorCount;
+    // pack the mid-layer weights into MFMA (16x16x4) register order:
+    //   wpack[l][wv][s][lane] = W[l][cout = 16wv + (lane&15)][cin][tap], k-step s = half*72 + tap*8 + c4,
+    //   cin = 32*half + 4*c4 + (lane>>4)
+    std::vector<float> pack((size_t)n_mid * 4 * 2 * KSTEPS_HALF * 64);
+    for (int l = 0; l < n_mid; ++l)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int s = 0; s < 2 * KSTEPS_HALF; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int half = s / KSTEPS_HALF, rs = s % KSTEPS_HALF, tap = rs / (HALF_C / 4), c4 = rs % (HALF_C / 4);
+                    const int cout = 16 * wv + (lane & 15), cin = HALF_C * half + 4 * c4 + (lane >> 4);
+                    pack[(((size_t)l * 4 + wv) * 2 * KSTEPS_HALF + s) * 64 + lane] =
+                        w_mid[(((size_t)l * C + cout) * C + cin) * 9 + tap];
+                }
+    const size_t act_bytes = (size_t)batch * C * H * W * sizeof(float);
+    hipError_t e = hipMalloc(&p->wpack, pack.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->wpack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->bias, (size_t)n_mid * C * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->bias, b_mid, (size_t)n_mid * C * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->w_first, C * 9 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->w_first, w_first, C * 9 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->w_last, C * 9 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->w_last, w_last, C * 9 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->act0, act_bytes);
+    if (e == hipSuccess) e = hipMalloc(&p->act1, act_bytes);
+    if (e == hipSuccess) e = hipMalloc(&p->zeros, 256);
+    if (e == hipSuccess) e = hipMemset(p->zeros, 0, 256);
+    if (e == hipSuccess) e = hipMalloc(&p->mm, (size_t)batch * 2 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->sse_part, (size_t)batch * (H * W / 256) * sizeof(double));
+    if (e != hipSuccess) {
+        set_error(std::string("pnp_dncnn_plan_create: ") + hipGetErrorString(e));
+        for (void* q : {(void*)p->wpack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
+                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part})
+            if (q) (void)hipFree(q);
+        delete p;
+        return PNP_ERR_HIP;
+    }
+    *out = p;
+    return PNP_OK;
+}
+
+extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
+    if (!p) return PNP_OK;
+    for (void* q : {(void*)p->wpack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
+                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part})
+        (void)hipFree(q);
+    delete p;
+    return PNP_OK;
+}
+
+namespace {
+template <typename T>
+int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net, T* z_out, float* r_out,
+              const T* xrec, double* sse_out, hipStream_t s) {
+    const int H = p->H, W = p->W, B = p->batch, HW = H * W;
+    T* mm = normalise ? (T*)p->mm : nullptr;             // raw network (no wrapper scaling): lo = 0, hi = 1
+    double srange = 1.0, sshift = 0.0;
+    if (normalise) {
+        k_minmax2<T><<<B, 256, 0, s>>>(z_in, HW, mm);
+        PNP_CHECK_LAUNCH();
+        srange = 1.0 + sigma_net / 255.0 / 2.0;
+        sshift = (1.0 - srange) / 2.0;
+    }
+    dim3 pg(HW / 256, B);
+    k_first<T><<<pg, 256, 0, s>>>(z_in, mm, p->w_first, p->act0, H, W, srange, sshift);
+    PNP_CHECK_LAUNCH();
+    const int ntiles = B * (H / TR) * (W / TC);
+    const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
+    float *src = p->act0, *dst = p->act1;
+    for (int l = 0; l < p->n_mid; ++l) {
+        k_mid<true><<<grid, 256, 0, s>>>(src, dst, p->wpack + (size_t)l * 4 * 2 * KSTEPS_HALF * 64, p->bias + (size_t)l * C,
+                                         p->zeros, H, W, ntiles);
+        PNP_CHECK_LAUNCH();
+        float* t = src; src = dst; dst = t;
+    }
+    k_last<T><<<pg, 256, 0, s>>>(src, p->w_last, z_in, mm, z_out, r_out, xrec, sse_out ? p->sse_part : nullptr, H, W,
+                                 srange, sshift);
+    PNP_CHECK_LAUNCH();
+    if (sse_out) {
+        k_sum_parts<<<B, 64, 0, s>>>(p->sse_part, HW / 256, sse_out);
+        PNP_CHECK_LAUNCH();
+    }
+    return PNP_OK;
+}
+}  // namespace
+
+extern "C" int pnp_dncnn_forward(pnp_dncnn_plan* p, const float* x, float* r, void* stream) {
+    PNP_CHECK_ARG(p && x && r, "null argument");
+    return run_dncnn<float>(p, x, false, 0.0, nullptr, r, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pnp_dncnn_denoise(pnp_dncnn_plan* p, const void* z_in, void* z_out, int dtype, double sigma_net,
+                                 const void* xrec, double* sse_out, void* stream) {
+    PNP_CHECK_ARG(p && z_in && z_out, "null argument");
+    PNP_CHECK_ARG(!(sse_out && !xrec), "sse_out needs xrec");
+    if (dtype == PNP_F32)
+        return run_dncnn<float>(p, (const float*)z_in, true, sigma_net, (float*)z_out, nullptr, (const float*)xrec, sse_out,
+                                (hipStream_t)stream);
+    if (dtype == PNP_F64)
+        return run_dncnn<double>(p, (const double*)z_in, true, sigma_net, (double*)z_out, nullptr, (const double*)xrec,
+                                 sse_out, (hipStream_t)stream);
+    PNP_CHECK_ARG(false, "bad dtype");
+}

@@ -73,6 +73,59 @@ class CsmriPlan:
         return out
 
 
+class DncnnPlan:
+    """pnp_dncnn_plan_*: DnCNN-17 prox for B images of H x W (fp32 network on the f32 matrix cores).
+
+    `weights`: dict of NumPy arrays in the reference's layer order -- conv{i}.weight (i = 0..n-1) and
+    bn{i}.{weight,bias,mean,var} for the middle layers -- exactly what tests/golden/dncnn_noise15.npz
+    holds or what `load_dncnn_state_dict` extracts from a reference .pth.  BatchNorm (eval) is folded here."""
+
+    def __init__(self, weights, H, W, batch):
+        import numpy as np
+        require_gpu()
+        n = int(weights['n_layers'])
+        self.H, self.W, self.B, self.n_mid = H, W, batch, n - 2
+        w_first = np.ascontiguousarray(weights['conv0.weight'], dtype=np.float32).reshape(64, 9)
+        w_last = np.ascontiguousarray(weights[f'conv{n - 1}.weight'], dtype=np.float32).reshape(64, 9)
+        w_mid = np.empty((n - 2, 64, 64, 9), dtype=np.float32)
+        b_mid = np.zeros((n - 2, 64), dtype=np.float32)
+        for i in range(1, n - 1):
+            w = np.asarray(weights[f'conv{i}.weight'], dtype=np.float64).reshape(64, 64, 9)
+            if f'bn{i}.weight' in weights:
+                s = np.asarray(weights[f'bn{i}.weight'], np.float64) / np.sqrt(np.asarray(weights[f'bn{i}.var'], np.float64) + 1e-5)
+                w = w * s[:, None, None]
+                b_mid[i - 1] = (np.asarray(weights[f'bn{i}.bias'], np.float64) - np.asarray(weights[f'bn{i}.mean'], np.float64) * s)
+            w_mid[i - 1] = w
+        h = ctypes.c_void_p()
+        N.call('pnp_dncnn_plan_create', ctypes.byref(h), n - 2, w_first.ctypes.data_as(ctypes.c_void_p),
+               w_mid.ctypes.data_as(ctypes.c_void_p), b_mid.ctypes.data_as(ctypes.c_void_p),
+               w_last.ctypes.data_as(ctypes.c_void_p), H, W, batch)
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                N.lib().pnp_dncnn_plan_destroy(h)
+            except Exception:
+                pass
+
+    def forward(self, x, out=None):
+        """raw network residual; x: float32 [B,H,W]."""
+        assert x.dtype == torch.float32 and tuple(x.shape) == (self.B, self.H, self.W)
+        out = out if out is not None else torch.empty_like(x)
+        N.call('pnp_dncnn_forward', self._h, _p(x), _p(out), _stream())
+        return out
+
+    def denoise(self, z, sigma_net, xrec=None, out=None, sse=None):
+        assert tuple(z.shape) == (self.B, self.H, self.W)
+        out = out if out is not None else torch.empty_like(z)
+        if xrec is not None and sse is None:
+            sse = torch.empty(self.B, dtype=torch.float64, device=z.device)
+        N.call('pnp_dncnn_denoise', self._h, _p(z), _p(out), _DT[z.dtype], float(sigma_net), _p(xrec), _p(sse), _stream())
+        return out, sse
+
+
 def sigma_est(z):
     """z: [B, H, W] -> [B] (estimate_sigma(multichannel=True, average_sigmas=True))."""
     require_gpu()

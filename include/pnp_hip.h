@@ -102,6 +102,12 @@ int pnp_dncnn_forward(pnp_dncnn_plan* plan, const float* x, float* r, void* stre
 int pnp_dncnn_denoise(pnp_dncnn_plan* plan, const void* z_in, void* z_out, int dtype, double sigma_net,
                       const void* xrec, double* sse_out, void* stream);
 
+/* In-band timing of the MFMA conv launches (measurement aid for bench.py): between begin and end
+ * every forward/denoise call brackets its n_mid conv launches with hipEvents on the caller's
+ * stream (no synchronisation until _end).  _end returns the mean duration of one conv launch.  */
+int pnp_dncnn_profile_begin(pnp_dncnn_plan* plan, int max_calls);
+int pnp_dncnn_profile_end(pnp_dncnn_plan* plan, double* avg_ms_per_launch, long* launches);
+
 /* ------------------------------------------------------------------ elementwise
  * out = a*x + b*y + c*w   (y, w may be NULL); n = total element count.
  * Covers z -= lr*v (pnp_gd.py:35), SAGA/SARAH combines (pnp_saga.py:47, pnp_sarah.py:72). */

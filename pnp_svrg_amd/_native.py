@@ -33,6 +33,8 @@ SIGNATURES = {
     'pnp_dncnn_plan_destroy': (_i, [_vp]),
     'pnp_dncnn_forward': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_dncnn_denoise': (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    'pnp_dncnn_profile_begin': (_i, [_vp, _i]),
+    'pnp_dncnn_profile_end': (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(ctypes.c_long)]),
     'pnp_axpbypcz': (_i, [_d, _vp, _d, _vp, _d, _vp, _vp, _sz, _i, _vp]),
 }
 

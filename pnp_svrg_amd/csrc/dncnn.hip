@@ -280,6 +280,12 @@ struct pnp_dncnn_plan {
     float *act0, *act1, *zeros;                  // [B][64][H][W] x2; a zero word for halo padding
     double* mm;                                  // [B][2] (as double or float depending on call)
     double* sse_part;                            // [B][H*W/256]
+    // optional in-band timing of the MFMA layers (hipEvents on the caller's stream, no sync)
+    bool profile;
+    std::vector<hipEvent_t> ev;                  // pairs: [2i] before, [2i+1] after the n_mid launches
+    size_t ev_used;
+    double prof_ms;
+    long prof_launches;
 };
 
 extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const float* w_first, const float* w_mid,
@@ -339,6 +345,7 @@ extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
     for (void* q : {(void*)p->wpack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
                     (void*)p->zeros, (void*)p->mm, (void*)p->sse_part})
         (void)hipFree(q);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
     return PNP_OK;
 }
@@ -362,12 +369,15 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     const int ntiles = B * (H / TR) * (W / TC);
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
     float *src = p->act0, *dst = p->act1;
+    const bool prof = p->profile && p->ev_used + 2 <= p->ev.size();
+    if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
     for (int l = 0; l < p->n_mid; ++l) {
         k_mid<true><<<grid, 256, 0, s>>>(src, dst, p->wpack + (size_t)l * 4 * 2 * KSTEPS_HALF * 64, p->bias + (size_t)l * C,
                                          p->zeros, H, W, ntiles);
         PNP_CHECK_LAUNCH();
         float* t = src; src = dst; dst = t;
     }
+    if (prof) { PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used + 1], s)); p->ev_used += 2; }
     k_last<T><<<pg, 256, 0, s>>>(src, p->w_last, z_in, mm, z_out, r_out, xrec, sse_out ? p->sse_part : nullptr, H, W,
                                  srange, sshift);
     PNP_CHECK_LAUNCH();
@@ -378,6 +388,32 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     return PNP_OK;
 }
 }  // namespace
+
+extern "C" int pnp_dncnn_profile_begin(pnp_dncnn_plan* p, int max_calls) {
+    PNP_CHECK_ARG(p && max_calls > 0, "bad argument");
+    while (p->ev.size() < (size_t)2 * max_calls) {
+        hipEvent_t e;
+        PNP_CHECK_HIP(hipEventCreate(&e));
+        p->ev.push_back(e);
+    }
+    p->profile = true; p->ev_used = 0; p->prof_ms = 0; p->prof_launches = 0;
+    return PNP_OK;
+}
+
+extern "C" int pnp_dncnn_profile_end(pnp_dncnn_plan* p, double* avg_ms_per_launch, long* launches) {
+    PNP_CHECK_ARG(p && avg_ms_per_launch && launches, "null argument");
+    p->profile = false;
+    for (size_t i = 0; i + 1 < p->ev_used; i += 2) {
+        PNP_CHECK_HIP(hipEventSynchronize(p->ev[i + 1]));
+        float ms = 0;
+        PNP_CHECK_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));
+        p->prof_ms += ms;
+        p->prof_launches += p->n_mid;
+    }
+    *launches = p->prof_launches;
+    *avg_ms_per_launch = p->prof_launches ? p->prof_ms / (double)p->prof_launches : 0.0;
+    return PNP_OK;
+}
 
 extern "C" int pnp_dncnn_forward(pnp_dncnn_plan* p, const float* x, float* r, void* stream) {
     PNP_CHECK_ARG(p && x && r, "null argument");

@@ -70,3 +70,88 @@ class BM3DDenoiser(Denoise):
 
     def denoise(self, noisy, sigma_est=0):
         raise NotImplementedError('BM3D is a third-party binary plug-in; not part of the MI355X hot path')
+
+
+# ------------------------------------------------------------------------------------------
+# DnCNN family (reference denoisers/RealSN_DnCNN.py + DeepDenoisers/utils/utils.py:10-33)
+# ------------------------------------------------------------------------------------------
+def dncnn_weights_from_state_dict(sd):
+    """Reference checkpoint (state dict of tensors) -> {'n_layers', 'conv{i}.weight', 'bn{i}.*'} arrays.
+
+    Handles the `module.` prefix nn.DataParallel left in the files and the RealSN layout: at
+    inference the spectral-norm hook just uses the stored `weight` buffer, so
+    `weight_orig` / `weight_u` are ignored."""
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+    conv_ids = sorted({int(k.split('.')[1]) for k, v in sd.items() if k.endswith('.weight') and v.dim() == 4})
+    out = {'n_layers': np.int64(len(conv_ids))}
+    for i, ci in enumerate(conv_ids):
+        out[f'conv{i}.weight'] = sd[f'dncnn.{ci}.weight'].detach().cpu().numpy().astype(np.float32)
+        bi = ci + 1
+        if f'dncnn.{bi}.running_mean' in sd:
+            out[f'bn{i}.weight'] = sd[f'dncnn.{bi}.weight'].cpu().numpy()
+            out[f'bn{i}.bias'] = sd[f'dncnn.{bi}.bias'].cpu().numpy()
+            out[f'bn{i}.mean'] = sd[f'dncnn.{bi}.running_mean'].cpu().numpy()
+            out[f'bn{i}.var'] = sd[f'dncnn.{bi}.running_var'].cpu().numpy()
+    return out
+
+
+def random_dncnn_weights(n_layers=17, seed=0):
+    """Random-init weights of the DnCNN-17 architecture (for synthetic benchmarks: there is no
+    network to fetch checkpoints).  He-style scaling keeps activations O(1) through 17 layers."""
+    rng = np.random.default_rng(seed)
+    w = {'n_layers': np.int64(n_layers)}
+    for i in range(n_layers):
+        cin = 1 if i == 0 else 64
+        cout = 1 if i == n_layers - 1 else 64
+        w[f'conv{i}.weight'] = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+        if 0 < i < n_layers - 1:
+            w[f'bn{i}.weight'] = (1.0 + 0.1 * rng.standard_normal(64)).astype(np.float32)
+            w[f'bn{i}.bias'] = (0.05 * rng.standard_normal(64)).astype(np.float32)
+            w[f'bn{i}.mean'] = (0.1 * rng.standard_normal(64)).astype(np.float32)
+            w[f'bn{i}.var'] = (1.0 + 0.2 * rng.random(64)).astype(np.float32)
+    return w
+
+
+def load_model(model_type, sigma):
+    """reference DeepDenoisers/utils/utils.py:10-33: same CWD-relative path and model types
+    ('DnCNN', 'SimpleCNN', 'RealSN_DnCNN', 'RealSN_SimpleCNN', anything else -> RealSN_DnCNN layout).
+    Returns the weight dict the MFMA plan consumes (there is no torch module on this path)."""
+    known = ('DnCNN', 'SimpleCNN', 'RealSN_DnCNN', 'RealSN_SimpleCNN')
+    path = "./denoisers/DeepDenoisers/Pretrained_models/" + model_type + "_noise" + str(sigma) + ".pth"
+    if model_type not in known:
+        path = "./denoisers/DeepDenoisers/Pretrained_models/" + str(model_type) + "_noise" + str(sigma) + ".pth"
+    sd = torch.load(path, map_location='cpu', weights_only=True)       # FileNotFoundError like the reference
+    return dncnn_weights_from_state_dict(sd)
+
+
+class RealSN_DnCNNDenoiser(Denoise):
+    """reference denoisers/RealSN_DnCNN.py:8-42.  `model_type`, `sigma` as in the reference; the
+    network runs as the MFMA conv stack of pnp_dncnn_* (fp32, like the reference's net).
+    Extension: `weights=` (a weight dict) bypasses the checkpoint file.  Like the reference this
+    denoiser ignores `sigma_est` and does not advance `t`."""
+
+    def __init__(self, model_type, sigma, *, weights=None):
+        super().__init__()
+        self.model_type = model_type
+        self.sigma = sigma
+        self.model = weights if weights is not None else load_model(self.model_type, self.sigma)
+        self._plans = {}
+
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key not in self._plans:
+            self._plans[key] = ops.DncnnPlan(self.model, H, W, B)
+        return self._plans[key]
+
+    def denoise_device(self, z, sigma_est=None, xrec=None, out=None, sse=None):
+        B, H, W = z.shape
+        out, sse = self._plan(B, H, W).denoise(z, self.sigma, xrec=xrec, out=out, sse=sse)
+        return out, sse, None
+
+    def denoise(self, noisy, sigma_est=0):
+        z = _as_dev(noisy)
+        H, W = z.shape[-2:]
+        out, _, _ = self.denoise_device(z.reshape(1, H, W))
+        if isinstance(noisy, torch.Tensor):
+            return out.reshape(noisy.shape)
+        return out.reshape(H, W).double().cpu().numpy()

@@ -1,0 +1,159 @@
+"""Batched, sync-free PnP-SVRG engine: B independent CSMRI reconstructions advance together,
+one inner iteration per `step()`, entirely in HBM.
+
+This is the throughput form of reference algorithms/pnp_svrg.py:26-95 (outer: mu = grad_full(z),
+w = z; inner: minibatch draw, SVRG direction, step, estimate_sigma, denoise, PSNR log) for the
+sweep-style workloads of script_diff_*_set12.py, where many reconstructions are independent.
+Nothing is read back per iteration: squared errors (for PSNR) accumulate in a device log.
+
+Minibatches are *inputs*: index lists [n_steps][B][mb] resident in HBM (drawn beforehand, from
+the legacy `np.random` stream when reference-identical draws are wanted, or from a fast
+Generator for synthetic benchmarks).
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+class CsmriBatch:
+    """Device-resident data of B CSMRI problems (reference problems/CSMRI.py:12-41 per problem)."""
+
+    def __init__(self, xrec, mask, Y, xinit, dtype=torch.float32, device='cuda'):
+        ops.require_gpu()
+        B, H, W = xrec.shape
+        self.B, self.H, self.W, self.N, self.dtype = B, H, W, H * W, dtype
+        cdt = torch.complex64 if dtype == torch.float32 else torch.complex128
+        self.plan = ops.CsmriPlan(H, W, B, dtype)
+        self.xrec = torch.from_numpy(np.ascontiguousarray(xrec, np.float64)).to(device, dtype)
+        self.xinit = torch.from_numpy(np.ascontiguousarray(xinit, np.float64)).to(device, dtype).reshape(B, H, W)
+        self.M0 = mask.reshape(B, -1).sum(1).astype(np.int64)
+        mask_u8 = torch.from_numpy(np.ascontiguousarray(mask, np.uint8)).to(device)
+        self.maskT = self.plan.sel_from_dense(mask_u8)
+        YT = torch.from_numpy(np.ascontiguousarray(np.swapaxes(Y, 1, 2))).to(device, cdt).contiguous()
+        self.yh_full = self.plan.pack_y(YT, self.maskT)
+        self.inv_m0 = None
+        if not np.all(self.M0 == self.M0[0]):
+            # per-problem 1/M0 differs: fold it into the data (grad_full is linear in 1/M0)
+            raise ValueError('CsmriBatch needs the same number of sampled k-space points in every problem; '
+                             'use synthetic(), which draws masks with a fixed count, or batch equal-M0 problems')
+        self.mask_np = np.ascontiguousarray(mask, np.uint8)
+
+    @classmethod
+    def synthetic(cls, B, H=256, W=256, sample_prob=0.2, snr=20.0, seed=0, dtype=torch.float32):
+        """B synthetic problems: smoothed-noise images, masks with exactly
+        round(p*N) sampled points (so 1/M0 is shared), complex data with real noise on the support."""
+        rng = np.random.default_rng(seed)
+        N = H * W
+        m0 = int(round(sample_prob * N))
+        xrec = np.empty((B, H, W))
+        mask = np.zeros((B, N), np.uint8)
+        Y = np.empty((B, H, W), np.complex128)
+        xinit = np.empty((B, N))
+        for b in range(B):
+            x = rng.random((H, W))
+            p = np.pad(x, 2, mode='wrap')
+            y = sum(p[i:i + H, j:j + W] for i in range(5) for j in range(5)) / 25.0
+            y = (y - y.min()) / (y.max() - y.min())
+            xrec[b] = np.round(y * 255) / 255.0
+            xrec[b] = (xrec[b] - xrec[b].min()) / (xrec[b].max() - xrec[b].min())
+            mask[b, rng.choice(N, m0, replace=False)] = 1
+            mk = mask[b].reshape(H, W)
+            Y0 = mk * np.fft.fft2(xrec[b])
+            sigma = np.sqrt(np.linalg.norm(Y0.ravel()) / 10 ** (snr / 10) / H / W)     # problem.py:58-61
+            Y[b] = Y0 + mk * rng.normal(0, sigma, (H, W))
+            xi = np.absolute(np.fft.ifft2(Y[b])).ravel()
+            xinit[b] = (xi - xi.min()) / (xi.max() - xi.min())
+        return cls(xrec, mask.reshape(B, H, W), Y, xinit, dtype=dtype)
+
+    def draw_minibatches(self, n_steps, mb, seed=1):
+        """[n_steps][B][mb] int32 flat k-space indices, each row a uniform draw without replacement
+        from that problem's mask support (CSMRI.py:66-74 semantics, fast Generator stream)."""
+        rng = np.random.default_rng(seed)
+        out = np.empty((n_steps, self.B, mb), np.int32)
+        for b in range(self.B):
+            locs = np.flatnonzero(self.mask_np[b]).astype(np.int32)
+            for s in range(n_steps):
+                out[s, b] = rng.choice(locs, mb, replace=False)
+        return torch.from_numpy(out).to(self.xrec.device)
+
+
+class TVProx:
+    """denoisers/TV.py semantics for the engine (fused estimate_sigma + BayesShrink + error sum)."""
+
+    def __init__(self, sigma_modifier=1.0, decay=1.0, denoise_strength=0.0):
+        self.sigma_modifier, self.decay, self.denoise_strength, self.t = sigma_modifier, decay, denoise_strength, 0
+
+    def bind(self, batch):
+        self.sig = torch.empty(batch.B, dtype=batch.dtype, device=batch.xrec.device)
+
+    def __call__(self, z, xrec, sse_out):
+        self.t += 1
+        ops.prox_tv(z, sigma_modifier=self.sigma_modifier, fallback_sigma=self.denoise_strength * self.decay ** self.t,
+                    xrec=xrec, out=z, sse=sse_out, sigma_out=self.sig)
+
+
+class DnCNNProx:
+    """denoisers/RealSN_DnCNN.py semantics for the engine.  The loop's estimate_sigma is still
+    evaluated (the reference computes it every iteration and this denoiser ignores it, F12)."""
+
+    def __init__(self, weights, sigma):
+        self.weights, self.sigma = weights, sigma
+
+    def bind(self, batch):
+        self.plan = ops.DncnnPlan(self.weights, batch.H, batch.W, batch.B)
+        self.sig = torch.empty(batch.B, dtype=batch.dtype, device=batch.xrec.device)
+        self.batch = batch
+
+    def __call__(self, z, xrec, sse_out):
+        from . import _native as N
+        import ctypes
+        b = self.batch
+        N.call('pnp_sigma_est', ctypes.c_void_p(z.data_ptr()), b.H, b.W, b.B, 0 if b.dtype == torch.float32 else 1,
+               ctypes.c_void_p(self.sig.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self.plan.denoise(z, self.sigma, xrec=xrec, out=z, sse=sse_out)
+
+
+class SvrgEngine:
+    """pnp_svrg over a CsmriBatch.  variant='svrg' is the true direction (pnp_svrg.py:53),
+    'reference' is what v1 executes (v = mu, :54).  `step(s)` = inner iteration s (the outer
+    full-gradient refresh happens inside when s % T2 == 0, as in the reference's loop nest)."""
+
+    def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096):
+        self.b, self.prox, self.eta, self.T2, self.mb, self.lr_decay, self.variant = batch, prox, eta, T2, mini_batch_size, lr_decay, variant
+        dev = batch.xrec.device
+        self.z = batch.xinit.clone()
+        self.w = torch.empty_like(self.z)
+        self.mu = torch.empty_like(self.z)
+        self.selT = torch.empty_like(batch.maskT)
+        self.sse_log = torch.zeros((n_log, batch.B), dtype=torch.float64, device=dev)
+        self.n_log = n_log
+        prox.bind(batch)
+        self.s = 0
+
+    def reset(self):
+        self.z.copy_(self.b.xinit)
+        self.s = 0
+        if hasattr(self.prox, 't'):
+            self.prox.t = 0
+
+    def step(self, idx_s):
+        """One inner iteration for all B problems.  idx_s: int32 [B][mb] minibatch indices."""
+        b, s = self.b, self.s
+        if s % self.T2 == 0:                                    # outer: mu = grad_full(z); w = z
+            b.plan.grad(self.z, b.maskT, yh=b.yh_full, alpha=1.0 / float(b.M0[0]), out=self.mu)
+            self.w.copy_(self.z)
+        lr = self.eta * self.lr_decay ** (s // self.T2)
+        if self.variant == 'svrg':
+            b.plan.sel_from_indices(idx_s, out=self.selT)
+            b.plan.grad(self.z, self.selT, b=self.w, alpha=-lr / self.mb, beta=1.0, c1=self.z, gamma=-lr, c2=self.mu, out=self.z)
+        else:
+            ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
+        self.prox(self.z, b.xrec, self.sse_log[s % self.n_log])
+        self.s += 1
+
+    def psnr_trace(self):
+        """[steps][B] PSNR (rounded to 0.01 dB like problems/problem.py:33-35), read back once."""
+        sse = self.sse_log[:min(self.s, self.n_log)].cpu().numpy()
+        with np.errstate(divide='ignore'):
+            return np.around(10 * np.log10(1.0 / (sse / self.b.N)), 2)

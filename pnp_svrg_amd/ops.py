@@ -110,6 +110,15 @@ class DncnnPlan:
             except Exception:
                 pass
 
+    def profile_begin(self, max_calls=4096):
+        N.call('pnp_dncnn_profile_begin', self._h, int(max_calls))
+
+    def profile_end(self):
+        """-> (mean ms of one 64->64 conv launch, number of launches timed)"""
+        ms, n = ctypes.c_double(), ctypes.c_long()
+        N.call('pnp_dncnn_profile_end', self._h, ctypes.byref(ms), ctypes.byref(n))
+        return ms.value, n.value
+
     def forward(self, x, out=None):
         """raw network residual; x: float32 [B,H,W]."""
         assert x.dtype == torch.float32 and tuple(x.shape) == (self.B, self.H, self.W)

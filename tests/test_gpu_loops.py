@@ -170,3 +170,38 @@ def test_tune_wrappers(api):
     assert r['status'] == 'ok' and r['loss'] == p.PSNR(p.Xinit) - p.PSNR(r['z'])
     r = A.tune_pnp_saga((5e2, 200, 0.1, 4), p, D.TVDenoiser(), tt=0.1)
     assert r['algo_name'] == 'pnp_saga'
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_svrg_dncnn_vs_oracle(api, dtype):
+    """BASELINE config 3 shape (CSMRI + DnCNN prox, pnp_svrg), 64x64, reference DnCNN weights:
+    the MFMA net inside the loop against the oracle loop with the torch-CPU fp32 net."""
+    from conftest import golden
+    from oracle import denoise as od, problems as op
+    A, P, D = api
+    wts = dict(golden('dncnn_noise15.npz'))
+    for variant in ('reference', 'svrg'):
+        p = _csmri(P, IMG64, 64, dtype)
+        np.random.seed(1)
+        r = A.pnp_svrg(p, D.RealSN_DnCNNDenoiser('DnCNN', 15, weights=wts), 5e2, 2 + 2 * (3 + 5 * 3), 3, 200,
+                       verbose=False, converge_check=False, clock=ol.CountingClock(), variant=variant)
+        np.random.seed(0)
+        po = op.CSMRI(IMG64, H=64, W=64, sample_prob=0.2, snr=20.)
+        np.random.seed(1)
+        ro = ol.pnp_svrg(po, od.DnCNNDenoiser(wts, 15), 5e2, 2 + 2 * (3 + 5 * 3), 3, 200, converge_check=False,
+                         clock=ol.CountingClock(), variant=variant)
+        ps, pso = np.array(r['psnr_per_iter']), np.array(ro['psnr_per_iter'])
+        assert len(ps) == len(pso) and np.abs(ps - pso).max() <= 0.01 + 1e-9
+        np.testing.assert_allclose(r['z'], ro['z'], rtol=0, atol=2e-4)
+
+
+def test_dncnn_denoiser_surface(api, g_denoise):
+    from conftest import golden
+    A, P, D = api
+    io = golden('dncnn_io.npz')
+    d = D.RealSN_DnCNNDenoiser('DnCNN', 15, weights=dict(golden('dncnn_noise15.npz')))
+    out = d.denoise(noisy=g_denoise['s64_z0'], sigma_est=123.0)       # sigma_est is ignored (F12)
+    assert d.t == 0 and out.shape == (64, 64) and out.dtype == np.float64
+    np.testing.assert_allclose(out, io['den64_s15'], rtol=0, atol=3e-5)
+    with pytest.raises(FileNotFoundError):                            # CWD-relative checkpoint path, as the reference
+        D.RealSN_DnCNNDenoiser('RealSN_DnCNN', 5)

@@ -34,46 +34,46 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int C = 64;             // feature channels
 constexpr int TR = 8, TC = 32;    // output tile rows / cols
-constexpr int PR = TR + 2, PC = TC + 2;
-constexpr int PLANE = PR * PC;    // 340 floats of halo tile per channel
-constexpr int PLANE_P = 368;      // padded plane stride: 368 % 32 == 16 -> the 4 k-rows of a B operand
-                                  // (lanes 0-15 / 16-31 of each half-wave) fall on disjoint LDS banks
+constexpr int PR = TR + 2;        // halo rows
+constexpr int PC = 40;            // halo row stride in LDS: columns [tx0-4, tx0+36) = ten 16-byte chunks,
+                                  // so every global->LDS piece is an aligned dwordx4 (the 3x3 halo needs
+                                  // only tx0-1 .. tx0+32; the 6 extra floats buy 4x fewer DMA instructions)
+constexpr int XOFF = 3;           // LDS column of image column tx0-1
+constexpr int PLANE = PR * PC;    // 400 floats per channel; 400 % 32 == 16 -> the 4 k-rows of a B operand
+                                  // (lanes 0-15 / 16-31 of a half-wave) fall on disjoint LDS banks
 constexpr int HALF_C = 32;        // channels per K-half
-constexpr int HALF_ELEMS = HALF_C * PLANE;            // 10880 payload floats per half
-constexpr int HALF_LDS = HALF_C * PLANE_P;            // 11776 floats = 46 KB per LDS buffer
-
+constexpr int HALF_LDS = HALF_C * PLANE;              // 12800 floats = 50 KB per LDS buffer
+constexpr int CHUNKS = HALF_LDS / 4;                  // 3200 16-byte chunks = 50 wave-pieces per half
 constexpr int KSTEPS_HALF = 9 * (HALF_C / 4);         // 72 MFMA K-steps (K=4 each) per half
 constexpr int MT = 16;                                // 16-pixel M-tiles per output tile (8 rows x 2)
 
-// Stage one K-half of an input halo tile global (NCHW) -> LDS by LDS-DMA (global_load_lds): no
-// staging registers, no ds_write.  One wave-instruction writes 64 consecutive floats of the LDS
-// image; the SOURCE address is per lane (halo rows are 34 floats; image borders read a zero word).
-// LDS image: [cin][PLANE_P] with the first 340 floats of each plane = [10][34] halo tile, so a
-// 64-float piece may straddle two planes: the per-lane source handles that, the destination is
-// contiguous only within a plane -> pieces are cut per plane (6 pieces of 64 cover 340 -> 384 slots,
-// the 44 surplus slots land in the plane's padding / are never read).
+// Stage one K-half of an input halo tile global (NCHW) -> LDS by LDS-DMA (global_load_lds_dwordx4):
+// no staging registers, no ds_write.  The LDS image [cin][10][40] is linear in the chunk index
+// q = cin*100 + row*10 + chunk, so one wave-instruction (64 lanes x 16 B) fills 64 consecutive
+// chunks; the SOURCE address is per lane; chunks outside the image read a zero line instead.
+__device__ __forceinline__ void dma_piece(int pc, const float* __restrict__ in, const float* __restrict__ zeros,
+                                          float* ldsbuf, int H, int W, int b, int ty0, int tx0, int half, int lane,
+                                          bool valid_tile) {
+    const int q = pc * 64 + lane;
+    const int cin = q / 100, r = q - cin * 100;
+    const int ry = r / 10, cx = r - ry * 10;
+    const int y = ty0 - 1 + ry, x = tx0 - 4 + 4 * cx;
+    const float* src = zeros;
+    if (valid_tile && y >= 0 && y < H && x >= 0 && x < W)
+        src = in + (((size_t)b * C + half * HALF_C + cin) * H + y) * W + x;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(ldsbuf + pc * 256), 16, 0, 0);
+}
+
+constexpr int PIECES = CHUNKS / 64;                   // 50 wave-pieces per half
+constexpr int PIECES_PER_WAVE = (PIECES + 3) / 4;     // 13 (the last one only for waves 0,1)
+
 __device__ __forceinline__ void dma_half(const float* __restrict__ in, const float* __restrict__ zeros,
                                          float* ldsbuf, int H, int W, int b, int ty0, int tx0, int half, int tid,
                                          bool valid_tile) {
     const int wv = tid >> 6, lane = tid & 63;
-    // 32 planes x 6 pieces = 192 pieces; wave wv takes pieces wv, wv+4, ...
 #pragma unroll 1
-    for (int pc = wv; pc < HALF_C * 6; pc += 4) {
-        const int cin = pc / 6, part = pc - cin * 6;
-        const int rem = part * 64 + lane;                       // position inside the plane
-        const float* src = zeros;
-        if (rem < PLANE) {
-            const int ry = rem / PC, rx = rem - ry * PC;
-            const int y = ty0 - 1 + ry, x = tx0 - 1 + rx;
-            if (valid_tile && y >= 0 && y < H && x >= 0 && x < W)
-                src = in + (((size_t)b * C + half * HALF_C + cin) * H + y) * W + x;
-        }
-        // last piece of a plane: 340 - 320 = 20 payload floats; slots 340..367 are padding, and
-        // slots 368..383 would spill into the next plane -> cut the piece to the padded stride
-        if (part < 5 || lane < PLANE_P - 320)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ldsbuf + cin * PLANE_P + part * 64), 4, 0, 0);
-    }
+    for (int pc = wv; pc < PIECES; pc += 4) dma_piece(pc, in, zeros, ldsbuf, H, W, b, ty0, tx0, half, lane, valid_tile);
 }
 
 template <bool RELU>
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = bias[16 * wv + 4 * (lane >> 4) + r];
 
-    const int lbase = (lane >> 4) * PLANE_P + (lane & 15);     // lane part of the B-operand LDS address
+    const int lbase = (lane >> 4) * PLANE + (lane & 15) + XOFF;     // lane part of the B-operand LDS address
 
     int tile = blockIdx.x;
     {
@@ -110,35 +110,53 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
 
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            // prefetch: the other K-half of this tile, or the first K-half of the next tile
+            // prefetch target: the other K-half of this tile, or the first K-half of the next tile
             float* nbuf = lds + (half ^ 1) * HALF_LDS;
-            if (half == 0) {
-                dma_half(in, zeros, nbuf, H, W, b, ty0, tx0, 1, tid, true);
-            } else {
-                const int nt = tile + gridDim.x;
-                const int nb = nt / tiles_per_img, n2 = nt - nb * tiles_per_img;
-                dma_half(in, zeros, nbuf, H, W, nb, (n2 / tiles_x) * TR, (n2 % tiles_x) * TC, 0, tid, nt < ntiles);
-            }
+            const int nt = tile + gridDim.x;
+            const int nb = half == 0 ? b : nt / tiles_per_img;
+            const int n2 = nt - nb * tiles_per_img;
+            const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
+            const bool nvalid = half == 0 ? true : nt < ntiles;
+
             const float* xb = lds + half * HALF_LDS + lbase;
+            // B operands of one (channel quad c4, dx) group: the 10 halo rows x 2 column halves; each
+            // value feeds up to three taps (dy): 20 LDS reads per 48 MFMAs.  Software pipeline: the reads
+            // of group g+1 and one DMA piece of the next buffer are issued underneath the MFMAs of group g.
+            float xr[2][PR][2];
+            constexpr int NG = (HALF_C / 4) * 3;           // 24 groups per half
 #pragma unroll
-            for (int c4 = 0; c4 < HALF_C / 4; ++c4) {
+            for (int ry = 0; ry < PR; ++ry)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    // the 10 halo rows x 2 column halves of this (channel quad, dx): each value feeds
-                    // up to three taps (dy) -> 20 ds_read_b32 per 48 MFMAs
-                    float xr[PR][2];
+                for (int h = 0; h < 2; ++h) xr[0][ry][h] = xb[ry * PC + 16 * h];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int c4 = g / 3, dx = g % 3;
+                if (g + 1 < NG) {
+                    const int c4n = (g + 1) / 3, dxn = (g + 1) % 3;
 #pragma unroll
                     for (int ry = 0; ry < PR; ++ry)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) xr[ry][h] = xb[(4 * c4) * PLANE_P + ry * PC + 16 * h + dx];
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int s = half * KSTEPS_HALF + (dy * 3 + dx) * (HALF_C / 4) + c4;
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], xr[(m >> 1) + dy][m & 1], acc[m], 0, 0, 0);
-                    }
+                        for (int h = 0; h < 2; ++h) xr[(g + 1) & 1][ry][h] = xb[(4 * c4n) * PLANE + ry * PC + 16 * h + dxn];
                 }
+                if (g < PIECES_PER_WAVE) {
+                    const int pc = wv + 4 * g;
+                    if (pc < PIECES) dma_piece(pc, in, zeros, nbuf, H, W, nb, nty0, ntx0, half ^ 1, lane, nvalid);
+                }
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int s = half * KSTEPS_HALF + (dy * 3 + dx) * (HALF_C / 4) + c4;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], xr[g & 1][(m >> 1) + dy][m & 1], acc[m], 0, 0, 0);
+                }
+                // interleave: 2 MFMA, then 1 LDS read (ds_read2 pairs count once), ... rest MFMA
+#pragma unroll
+                for (int i = 0; i < 20; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                                // next buffer landed (vmcnt(0)) + everyone done reading
         }

@@ -214,6 +214,11 @@ __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T*
 
 // ------------------------------------------------------------------------------- last layer
 // r = sum_{c,t} w[c][t] * act[c][tap t];  x = xt - r;  x = (x - sshift)/srange;  z = x*(hi-lo)+lo
+// HBM/L2-bound (reads the 64-channel activation once): 16 x 64 output tile per workgroup, 8 channels
+// at a time staged in LDS as [8][18][72] (columns tx0-4 .. tx0+67, 16-byte aligned rows), every
+// thread owns a 1 x 4 pixel strip: one ds_read_b128 + two ds_read_b32 per row and channel.
+constexpr int LT_R = 16, LT_C = 64, LT_CK = 8, LT_PR = LT_R + 2, LT_PC = LT_C + 8;
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_last(const float* __restrict__ act, const float* __restrict__ w,
                                               const T* __restrict__ zin, const T* __restrict__ mm,
@@ -221,42 +226,74 @@ __global__ __launch_bounds__(256) void k_last(const float* __restrict__ act, con
                                               const T* __restrict__ xrec, double* __restrict__ sse_part, int H, int W,
                                               double srange, double sshift) {
     __shared__ float ws[C * 9];
+    __shared__ __attribute__((aligned(16))) float tile[LT_CK * LT_PR * LT_PC];
     __shared__ double red[4];
-    for (int i = threadIdx.x; i < C * 9; i += 256) ws[i] = w[i];
-    __syncthreads();
-    const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const int y = p / W, x = p - y * W;
-    float r = 0.f;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C * 9; i += 256) ws[i] = w[i];
+    const int b = blockIdx.z;
+    const int ty0 = blockIdx.y * LT_R, tx0 = blockIdx.x * LT_C;
+    const int py = tid >> 4, px = (tid & 15) * 4;               // this thread's strip inside the tile
     const float* ab = act + (size_t)b * C * H * W;
-    for (int c = 0; c < C; ++c) {
-        const float* ac = ab + (size_t)c * H * W;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < C; c0 += LT_CK) {
+        __syncthreads();
+        // stage [8 ch][18 rows][18 float4]
+        for (int i = tid; i < LT_CK * LT_PR * (LT_PC / 4); i += 256) {
+            const int ch = i / (LT_PR * (LT_PC / 4)), rem = i - ch * (LT_PR * (LT_PC / 4));
+            const int ry = rem / (LT_PC / 4), cx = rem - ry * (LT_PC / 4);
+            const int y = ty0 - 1 + ry, x = tx0 - 4 + 4 * cx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < H && x >= 0 && x < W)
+                v = *reinterpret_cast<const float4*>(ab + ((size_t)(c0 + ch) * H + y) * W + x);
+            *reinterpret_cast<float4*>(tile + (ch * LT_PR + ry) * LT_PC + 4 * cx) = v;
+        }
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) r = fmaf(ws[c * 9 + t], ac[yy * W + xx], r);
+        for (int ch = 0; ch < LT_CK; ++ch) {
+            const float* wc = ws + (c0 + ch) * 9;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* row = tile + (ch * LT_PR + py + dy) * LT_PC + px + 4;     // LDS col of pixel px
+                const float4 m = *reinterpret_cast<const float4*>(row);
+                const float l = row[-1], rr = row[4];
+                const float w0 = wc[dy * 3], w1 = wc[dy * 3 + 1], w2 = wc[dy * 3 + 2];
+                r[0] = fmaf(w0, l, fmaf(w1, m.x, fmaf(w2, m.y, r[0])));
+                r[1] = fmaf(w0, m.x, fmaf(w1, m.y, fmaf(w2, m.z, r[1])));
+                r[2] = fmaf(w0, m.y, fmaf(w1, m.z, fmaf(w2, m.w, r[2])));
+                r[3] = fmaf(w0, m.z, fmaf(w1, m.w, fmaf(w2, rr, r[3])));
+            }
         }
     }
     double err = 0.0;
-    if (r_out != nullptr) r_out[(size_t)b * H * W + p] = r;
-    if (zout != nullptr) {
-        const T lo = mm[2 * b], hi = mm[2 * b + 1];
-        T v = (zin[(size_t)b * H * W + p] - lo) / (hi - lo);
-        v = v * (T)srange + (T)sshift;                      // xtilde, kept in T (f64 in the reference wrapper)
-        v = v - (T)r;                                       // f64 - f32 in the reference wrapper
-        v = (v - (T)sshift) / (T)srange;
-        v = v * (hi - lo) + lo;
-        zout[(size_t)b * H * W + p] = v;
-        if (xrec != nullptr) {
-            const double d = (double)xrec[(size_t)b * H * W + p] - (double)v;
-            err = d * d;
+    const int y = ty0 + py;
+    if (y < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = tx0 + px + j;
+            if (x >= W) continue;
+            const size_t p = (size_t)b * H * W + (size_t)y * W + x;
+            if (r_out != nullptr) r_out[p] = r[j];
+            if (zout != nullptr) {
+                const T lo = mm[2 * b], hi = mm[2 * b + 1];
+                T v = (zin[p] - lo) / (hi - lo);
+                v = v * (T)srange + (T)sshift;                  // xtilde, kept in T (f64 in the reference wrapper)
+                v = v - (T)r[j];                                // f64 - f32 in the reference wrapper
+                v = (v - (T)sshift) / (T)srange;
+                v = v * (hi - lo) + lo;
+                zout[p] = v;
+                if (xrec != nullptr) {
+                    const double d = (double)xrec[p] - (double)v;
+                    err += d * d;
+                }
+            }
         }
     }
     if (sse_part != nullptr) {
         err = wave_sum(err);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = err;
+        if ((tid & 63) == 0) red[tid >> 6] = err;
         __syncthreads();
-        if (threadIdx.x == 0) sse_part[(size_t)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (tid == 0)
+            sse_part[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -396,11 +433,12 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
         float* t = src; src = dst; dst = t;
     }
     if (prof) { PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used + 1], s)); p->ev_used += 2; }
-    k_last<T><<<pg, 256, 0, s>>>(src, p->w_last, z_in, mm, z_out, r_out, xrec, sse_out ? p->sse_part : nullptr, H, W,
+    dim3 lg((W + LT_C - 1) / LT_C, (H + LT_R - 1) / LT_R, B);
+    k_last<T><<<lg, 256, 0, s>>>(src, p->w_last, z_in, mm, z_out, r_out, xrec, sse_out ? p->sse_part : nullptr, H, W,
                                  srange, sshift);
     PNP_CHECK_LAUNCH();
     if (sse_out) {
-        k_sum_parts<<<B, 64, 0, s>>>(p->sse_part, HW / 256, sse_out);
+        k_sum_parts<<<B, 64, 0, s>>>(p->sse_part, (int)(lg.x * lg.y), sse_out);
         PNP_CHECK_LAUNCH();
     }
     return PNP_OK;

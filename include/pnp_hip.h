@@ -60,6 +60,33 @@ int pnp_csmri_grad(pnp_csmri_plan* plan, const void* a, const void* b, const uin
                    const void* yh, double alpha, double beta, const void* c1,
                    double gamma, const void* c2, void* out, void* stream);
 
+/* ------------------------------------------------------------------ Deblur / super-resolution
+ * Replaces problems/DeblurSR.py:119-147: 1-D circular blur of the raveled image via a length-H*W FFT
+ * (spectrum of the kernel computed once at plan creation), optional 4-tap bilinear down-sampler
+ * (pylops Bilinear semantics; its adjoint as a deterministic CSR gather).  H*W in {4096, 65536}.
+ * Plan-creation arrays are HOST pointers: Bk [H*W] blur kernel (DeblurSR.py:93, already / N, `dtype`);
+ * for scale_percent == 100 pass M = H*W and NULL operators; else g_idx/g_w [M][4] (forward taps) and
+ * a_rowptr [H*W+1], a_col/a_val [nnz] (CSR of the adjoint).                                       */
+typedef struct pnp_deblur_plan pnp_deblur_plan;
+int pnp_deblur_plan_create(pnp_deblur_plan** plan, int H, int W, int batch, int dtype, const void* Bk, int M,
+                           const int32_t* g_idx, const void* g_w, const int32_t* a_rowptr,
+                           const int32_t* a_col, const void* a_val);
+int pnp_deblur_plan_destroy(pnp_deblur_plan* plan);
+/* out = scale * B^T S^T ( sel o (S B z - Y) )   (grad_full: sel = NULL, scale = 1/M; grad_stoch:
+ * sel = minibatch indicator uint8 [batch][M], scale = 1).  z, out [batch][H*W]; Y [batch][M].   */
+int pnp_deblur_grad(pnp_deblur_plan* plan, const void* z, const void* Y, const uint8_t* sel, double scale,
+                    void* out, void* stream);
+/* forward model S B x (DeblurSR.py:110-112): out [batch][M]                                     */
+int pnp_deblur_forward(pnp_deblur_plan* plan, const void* x, void* out, void* stream);
+
+/* ------------------------------------------------------------------ phase retrieval
+ * Replaces problems/PR.py:75-87.  A [M][N] row-major, w [N], y [M] (device, `dtype`).
+ * out = scale * A_sel^T ( ((|A_sel w| - y_sel)/|A_sel w|) o A_sel w ); rows int32 [nsel] or NULL (all).
+ * workspace: pnp_pr_workspace_elems(M, N) elements of `dtype`.                                  */
+size_t pnp_pr_workspace_elems(int M, int N);
+int pnp_pr_grad(const void* A, const void* w, const void* y, const int32_t* rows, int nsel, int M, int N,
+                int dtype, double scale, void* workspace, void* out, void* stream);
+
 /* ------------------------------------------------------------------ prox / noise estimate
  * estimate_sigma(z0, multichannel=True, average_sigmas=True) (algorithms/pnp_svrg.py:71):
  * per-column db2 MAD, mean over columns.  sigma_out: [batch] (dtype).                    */
@@ -75,6 +102,20 @@ int pnp_sigma_est(const void* z, int H, int W, int batch, int dtype, void* sigma
 int pnp_prox_tv(const void* z_in, void* z_out, int H, int W, int batch, int dtype,
                 const void* sigma_in, double sigma_modifier, double fallback_sigma,
                 const void* xrec, double* sse_out, void* sigma_out, void* stream);
+
+/* NLMDenoiser.denoise (denoisers/NLM.py:22-27 -> skimage 0.18 _nl_means_denoising_2d, slow mode,
+ * Schraudolph fast_exp).  patch_size as the caller passes it (even sizes are bumped to the
+ * next odd one like skimage: 4 -> 5; supported sides 3/5/7), patch_distance in [1, 8].
+ *   sigma_in != NULL : h = sigma = sigma_in[b]*sigma_modifier, var = 2 sigma^2   (NLM.py:25)
+ *   sigma_in == NULL : h = fixed_h, var = 0                                     (NLM.py:27)
+ *   w0 [side*side] (device, double) = exp(-(x^2+y^2)/(2A^2)), A = (side-1)/4, and w0_sum = its sum as
+ *   NumPy computes it (the caller builds both once: bit-for-bit the reference's normalisation).
+ *   z_out must not alias z_in.  sse_out [batch] double (optional; needs xrec and sse_workspace of
+ *   batch*ceil(H/16)*ceil(W/16) doubles).                                                     */
+int pnp_nlm2d(const void* z_in, void* z_out, int H, int W, int batch, int dtype, int patch_size,
+              int patch_distance, const void* sigma_in, double sigma_modifier, double fixed_h,
+              const double* w0, double w0_sum, const void* xrec, double* sse_out, double* sse_workspace,
+              void* stream);
 
 /* sum (xrec - z)^2 per problem (Problem.PSNR, problems/problem.py:33-35). sse_out: [batch] double */
 int pnp_sse(const void* z, const void* xrec, int n_per_problem, int batch, int dtype, double* sse_out, void* stream);

@@ -25,8 +25,15 @@ SIGNATURES = {
     'pnp_csmri_sel_from_dense': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_csmri_pack_y': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pnp_csmri_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _d, _vp, _vp, _vp]),
+    'pnp_deblur_plan_create': (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    'pnp_deblur_plan_destroy': (_i, [_vp]),
+    'pnp_deblur_grad': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp]),
+    'pnp_deblur_forward': (_i, [_vp, _vp, _vp, _vp]),
+    'pnp_pr_workspace_elems': (_sz, [_i, _i]),
+    'pnp_pr_grad': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
     'pnp_sigma_est': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'pnp_prox_tv': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _d, _d, _vp, _vp, _vp, _vp]),
+    'pnp_nlm2d': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _d, _d, _vp, _d, _vp, _vp, _vp, _vp]),
     'pnp_sse': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'pnp_minmax': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'pnp_dncnn_plan_create': (_i, [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _i, _i, _i]),

@@ -269,18 +269,22 @@ template <bool DENOISE>
 int dispatch_prox(const void* zin, void* zout, int H, int W, int batch, int dtype, const void* sigma_in, double mod,
                   double fb, const void* xrec, double* sse, void* sigma_out, hipStream_t s) {
     PNP_CHECK_ARG(zin != nullptr && batch >= 1, "null input / empty batch");
-    PNP_CHECK_ARG(H == 64 || H == 128 || H == 256, "H must be 64, 128 or 256");
+    PNP_CHECK_ARG(H == 16 || H == 32 || H == 64 || H == 128 || H == 256, "H must be 16, 32, 64, 128 or 256");
     PNP_CHECK_ARG(W % 16 == 0 && W >= 16 && W <= 256, "W must be a multiple of 16 in [16, 256]");
     PNP_CHECK_ARG(dtype == PNP_F32 || dtype == PNP_F64, "bad dtype");
 #define PNP_PROX_CASE(TT, HH) return launch_prox<TT, HH, DENOISE>(zin, zout, W, batch, sigma_in, mod, fb, xrec, sse, sigma_out, s)
     if (dtype == PNP_F32) {
         if (H == 256) PNP_PROX_CASE(float, 256);
         if (H == 128) PNP_PROX_CASE(float, 128);
-        PNP_PROX_CASE(float, 64);
+        if (H == 64) PNP_PROX_CASE(float, 64);
+        if (H == 32) PNP_PROX_CASE(float, 32);
+        PNP_PROX_CASE(float, 16);
     }
     if (H == 256) PNP_PROX_CASE(double, 256);
     if (H == 128) PNP_PROX_CASE(double, 128);
-    PNP_PROX_CASE(double, 64);
+    if (H == 64) PNP_PROX_CASE(double, 64);
+    if (H == 32) PNP_PROX_CASE(double, 32);
+    PNP_PROX_CASE(double, 16);
 #undef PNP_PROX_CASE
 }
 

@@ -155,3 +155,44 @@ class RealSN_DnCNNDenoiser(Denoise):
         if isinstance(noisy, torch.Tensor):
             return out.reshape(noisy.shape)
         return out.reshape(H, W).double().cpu().numpy()
+
+
+class NLMDenoiser(Denoise):
+    """reference denoisers/NLM.py:9-27 (skimage slow-mode non-local means) on the MI355X.
+    Like the reference, `denoise` reads `self.sigma`, which the constructor does not set:
+    callers assign `denoiser.sigma` first, otherwise AttributeError -- kept for drop-in parity."""
+
+    def __init__(self, decay=1, denoise_strength=0, patch_size=4, patch_distance=5, sigma_modifier=1, fast_mode=False,
+                 multichannel=True, dtype=None):
+        super().__init__()
+        if fast_mode:
+            raise NotImplementedError('fast_mode=True (integral-image NLM) is not on the reference hot path')
+        self.decay = decay
+        self.denoise_strength = denoise_strength
+        self.fast_mode = fast_mode
+        self.sigma_modifier = sigma_modifier
+        self.patch = dict(patch_size=patch_size, patch_distance=patch_distance, multichannel=multichannel)
+        self.dtype = dtype
+
+    def denoise_device(self, z, sigma_est=None, xrec=None):
+        """z [B,H,W]; sigma_est: device tensor [B] or None (estimated on the device first)."""
+        self.t += 1
+        ps, pd = self.patch['patch_size'], self.patch['patch_distance']
+        if self.sigma > 0:
+            if sigma_est is None:
+                sigma_est = ops.sigma_est(z)
+            out, sse = ops.nlm2d(z, sigma_in=sigma_est, sigma_modifier=self.sigma_modifier, patch_size=ps,
+                                 patch_distance=pd, xrec=xrec)
+        else:
+            out, sse = ops.nlm2d(z, fixed_h=self.denoise_strength * self.decay ** self.t, patch_size=ps,
+                                 patch_distance=pd, xrec=xrec)
+        return out, sse, sigma_est
+
+    def denoise(self, noisy, sigma_est=0):
+        z = _as_dev(noisy, self.dtype)
+        H, W = z.shape[-2:]
+        s = torch.full((1,), float(sigma_est), dtype=z.dtype, device=z.device)
+        out, _, _ = self.denoise_device(z.reshape(1, H, W), sigma_est=s)
+        if isinstance(noisy, torch.Tensor):
+            return out.reshape(noisy.shape)
+        return out.reshape(H, W).double().cpu().numpy()

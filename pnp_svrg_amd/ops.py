@@ -179,3 +179,90 @@ def axpbypcz(a, x, b=0.0, y=None, c=0.0, w=None, out=None):
     out = out if out is not None else torch.empty_like(x)
     N.call('pnp_axpbypcz', float(a), _p(x), float(b), _p(y), float(c), _p(w), _p(out), x.numel(), _DT[x.dtype], _stream())
     return out
+
+
+_NLM_W0 = {}
+
+
+def _nlm_w0(side, device):
+    """exp(-(x^2+y^2)/(2A^2)), A=(side-1)/4, and its NumPy sum (skimage non_local_means.py:150-153)."""
+    key = (side, str(device))
+    if key not in _NLM_W0:
+        import numpy as np
+        off = side // 2
+        A = (side - 1.0) / 4.0
+        g = np.arange(-off, off + 1)
+        gr, gc = np.meshgrid(g, g, indexing='ij')
+        w = np.exp(-(gr * gr + gc * gc) / (2 * A * A))
+        _NLM_W0[key] = (torch.from_numpy(np.ascontiguousarray(w.ravel())).to(device), float(np.sum(w)))
+    return _NLM_W0[key]
+
+
+def nlm2d(z, sigma_in=None, sigma_modifier=1.0, fixed_h=0.0, patch_size=4, patch_distance=5, xrec=None, out=None, sse=None):
+    """skimage denoise_nl_means(slow mode) semantics on [B,H,W]; returns (denoised, sse or None)."""
+    require_gpu()
+    B, H, W = z.shape
+    side = patch_size + 1 if patch_size % 2 == 0 else patch_size
+    w0, w0_sum = _nlm_w0(side, z.device)
+    out = out if out is not None else torch.empty_like(z)
+    ws = None
+    if xrec is not None:
+        sse = sse if sse is not None else torch.empty(B, dtype=torch.float64, device=z.device)
+        ws = torch.empty(B * ((H + 15) // 16) * ((W + 15) // 16), dtype=torch.float64, device=z.device)
+    N.call('pnp_nlm2d', _p(z), _p(out), H, W, B, _DT[z.dtype], int(patch_size), int(patch_distance), _p(sigma_in),
+           float(sigma_modifier), float(fixed_h), _p(w0), w0_sum, _p(xrec), _p(sse), _p(ws), _stream())
+    return out, sse
+
+
+class DeblurPlan:
+    """pnp_deblur_plan_*: B^T S^T (S B z - y) for B problems of H x W (H*W in {4096, 65536})."""
+
+    def __init__(self, H, W, batch, dtype, Bk, bilinear=None):
+        import numpy as np
+        require_gpu()
+        self.H, self.W, self.N, self.B, self.dtype = H, W, H * W, batch, dtype
+        npdt = np.float32 if dtype == torch.float32 else np.float64
+        Bk = np.ascontiguousarray(Bk, dtype=npdt)
+        h = ctypes.c_void_p()
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        if bilinear is None:
+            self.M = self.N
+            N.call('pnp_deblur_plan_create', ctypes.byref(h), H, W, batch, _DT[dtype], vp(Bk), self.M, None, None, None, None, None)
+        else:
+            g_idx, g_w, a_rowptr, a_col, a_val = bilinear
+            self.M = g_idx.shape[0]
+            keep = [np.ascontiguousarray(g_idx, np.int32), np.ascontiguousarray(g_w, npdt), np.ascontiguousarray(a_rowptr, np.int32),
+                    np.ascontiguousarray(a_col, np.int32), np.ascontiguousarray(a_val, npdt)]
+            N.call('pnp_deblur_plan_create', ctypes.byref(h), H, W, batch, _DT[dtype], vp(Bk), self.M, *[vp(k) for k in keep])
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                N.lib().pnp_deblur_plan_destroy(h)
+            except Exception:
+                pass
+
+    def grad(self, z, Y, sel=None, scale=1.0, out=None):
+        assert z.dtype == self.dtype and z.numel() == self.B * self.N and Y.numel() == self.B * self.M
+        out = out if out is not None else torch.empty_like(z)
+        N.call('pnp_deblur_grad', self._h, _p(z), _p(Y), _p(sel), float(scale), _p(out), _stream())
+        return out
+
+    def forward(self, x, out=None):
+        out = out if out is not None else torch.empty(self.B * self.M, dtype=self.dtype, device=x.device)
+        N.call('pnp_deblur_forward', self._h, _p(x), _p(out), _stream())
+        return out
+
+
+def pr_grad(A, w, y, rows=None, scale=1.0, workspace=None, out=None):
+    """scale * A_sel^T(((|A_sel w| - y_sel)/|A_sel w|) o A_sel w); A [M,N], rows int32 [nsel] or None."""
+    require_gpu()
+    M, Nn = A.shape
+    if workspace is None:
+        workspace = torch.empty(N.lib().pnp_pr_workspace_elems(M, Nn), dtype=A.dtype, device=A.device)
+    out = out if out is not None else torch.empty(Nn, dtype=A.dtype, device=A.device)
+    nsel = M if rows is None else rows.numel()
+    N.call('pnp_pr_grad', _p(A), _p(w), _p(y), _p(rows), nsel, M, Nn, _DT[A.dtype], float(scale), _p(workspace), _p(out), _stream())
+    return out

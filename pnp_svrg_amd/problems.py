@@ -209,3 +209,164 @@ class CSMRI(Problem):
         selT = self._selector(mb)
         return self.plan.grad(z.reshape(shp), selT, b=w.reshape(shp), alpha=alpha, beta=beta, c1=c1,
                               gamma=gamma, c2=c2, out=out)
+
+
+def _bilinear_taps(iava, dims):
+    """pylops 1.14 `signalprocessing.Bilinear(iava, dims)` restated from its published semantics
+    (floor index + fractional weights, 4 taps; adjoint = transposed taps).  pylops itself is not
+    available in the build container: parity of this operator is UNPINNED (adjoint dot-test only)."""
+    ncols = dims[1]
+    r0 = np.floor(iava[0]).astype(np.int64)
+    c0 = np.floor(iava[1]).astype(np.int64)
+    wr, wc = iava[0] - r0, iava[1] - c0
+    idx = np.stack([r0 * ncols + c0, (r0 + 1) * ncols + c0, r0 * ncols + c0 + 1, (r0 + 1) * ncols + c0 + 1], axis=1)
+    wts = np.stack([(1 - wr) * (1 - wc), wr * (1 - wc), (1 - wr) * wc, wr * wc], axis=1)
+    M, N = idx.shape[0], dims[0] * dims[1]
+    # CSR of the adjoint: for every image pixel the (measurement, weight) pairs that touch it
+    flat_t = idx.ravel()
+    order = np.argsort(flat_t, kind='stable')
+    a_col = (np.arange(M * 4) // 4)[order].astype(np.int32)
+    a_val = wts.ravel()[order]
+    a_rowptr = np.zeros(N + 1, np.int32)
+    np.add.at(a_rowptr, flat_t + 1, 1)
+    a_rowptr = np.cumsum(a_rowptr).astype(np.int32)
+    return idx.astype(np.int32), wts, a_rowptr, a_col, a_val
+
+
+class Deblur(Problem):
+    """reference problems/DeblurSR.py:16-147 with forward model and gradients on the MI355X."""
+    eps = 1e-10
+
+    def __init__(self, img_path=None, H=64, W=64, kernel_path=None, kernel=None, scale_percent=50, snr=None,
+                 sigma=None, **ext):
+        super().__init__(img_path, H, W, **ext)
+        self.pname = 'deblur'
+        self.scale_percent = scale_percent
+        self.snr = snr
+        self.sigma = sigma
+        self.kernel_path = kernel_path
+        self.kernel = kernel
+        if kernel_path is None and kernel is None:
+            raise Exception('Need to pass in kernel path or kernel as image')
+        self._load_kernel()
+        self.lrH = int(self.H * scale_percent / 100)
+        self.lrW = int(self.W * scale_percent / 100)
+        self.M = self.lrH * self.lrW
+        self._generate_bop()
+        self.Y0 = self.forward_model(self.X)
+        self.set_snr_sigma()
+        noises = np.random.normal(0, self.sigma, self.Y0.shape)
+        self.Y = self.Y0 + noises
+        self.Xinit = np.random.uniform(0.0, 1.0, self.N)
+        self._Y_d = self.to_device(self.Y).reshape(1, self.M)
+
+    def _load_kernel(self):
+        if self.kernel_path is not None:
+            from PIL import Image
+            self.B = np.array(Image.open(self.kernel_path).resize((self.H, self.W)))
+        elif isinstance(self.kernel, str) and self.kernel == "Identity":
+            self.B = np.zeros(self.N)
+            self.B[0] = 1
+        elif isinstance(self.kernel, str) and self.kernel == "Minimal":
+            self.B = np.zeros((self.H, self.W))
+            self.B[0, 0] = 1
+            self.B[self.H // 2, self.H // 2] = 1
+            self.B[self.H // 2, self.H // 3] = 1
+            self.B[self.H // 2, self.H // 4] = 1
+            self.B /= 4
+        elif self.kernel is not None:
+            self.B = self.kernel
+        else:
+            raise Exception('Need to pass in blur kernel path or kernel')
+        self.B = np.asarray(self.B).ravel() / self.N
+
+    def _generate_bop(self):
+        taps = None
+        if self.scale_percent != 100:
+            ptsH = np.linspace(self.eps, self.H - (1 + self.eps), self.lrH)
+            ptsW = np.linspace(self.eps, self.W - (1 + self.eps), self.lrW)
+            meshW, meshH = np.meshgrid(ptsH, ptsW)                    # (sic) as DeblurSR.py:102
+            iava = np.vstack([meshH.ravel(), meshW.ravel()])
+            taps = _bilinear_taps(iava, (self.H, self.W))
+        self.Bop = taps                                               # forward taps + CSR adjoint (None = Identity)
+        self.plan = ops.DeblurPlan(self.H, self.W, 1, self.dtype, self.B, bilinear=taps)
+
+    def forward_model(self, w):
+        wd = (w if self._is_dev(w) else self.to_device(w)).reshape(1, self.N)
+        y = self.plan.forward(wd)
+        return y if self._is_dev(w) else y.double().cpu().numpy()
+
+    def f(self, w):
+        w = w.double().cpu().numpy() if self._is_dev(w) else w
+        return np.linalg.norm(self.Y - self.forward_model(w)) ** 2 / 2 / self.M
+
+    def grad_full(self, z):
+        zd = (z if self._is_dev(z) else self.to_device(z)).reshape(1, self.N)
+        g = self.plan.grad(zd, self._Y_d, scale=1.0 / self.M)
+        return self._ret(g.reshape(-1), z)
+
+    def grad_stoch(self, z, mb, *, scale=1.0):
+        zd = (z if self._is_dev(z) else self.to_device(z)).reshape(1, self.N)
+        sel = torch.from_numpy(np.ascontiguousarray(np.asarray(mb).ravel() != 0).astype(np.uint8)).to(self.device).reshape(1, self.M)
+        g = self.plan.grad(zd, self._Y_d, sel=sel, scale=scale)
+        return self._ret(g.reshape(-1), z)
+
+
+class PhaseRetrieval(Problem):
+    """reference problems/PR.py:12-87 with the amplitude-flow gradients on the MI355X.  Setup
+    (Gaussian A from the legacy np.random stream, spectral initialisation by power iteration,
+    PR.py:26-63) is one-off and stays in NumPy float64."""
+
+    def __init__(self, img_path=None, H=256, W=256, num_meas=-1, snr=None, sigma=None, **ext):
+        super().__init__(img_path, H, W, **ext)
+        self.pname = 'pr'
+        self.M = num_meas
+        self.snr = snr
+        self.sigma = sigma
+        self.A = np.random.randn(self.M, self.N)
+        self.Y0 = np.absolute(self.A.dot(self.X)).ravel()
+        self.set_snr_sigma()
+        noises = np.random.normal(0, self.sigma, self.Y0.shape)
+        self.Y = self.Y0 + noises
+        self.SNR = self.get_snr_from_sigma
+        self.spec_init()
+        self.Xinit = (self.Xinit - self.Xinit.min()) / (self.Xinit.max() - self.Xinit.min())
+        self._A_d = self.to_device(self.A)
+        self._Y_d = self.to_device(self.Y)
+        self._ws = None
+
+    def spec_init(self):
+        nrm = np.linalg.norm(self.X)
+        D = self.A.T.dot(self.A * self.Y[:, None]) / self.M
+        m, mold = 1, 2
+        y_final, y_old = 2 * np.ones(self.N), np.ones(self.N)
+        tol = 1e-5
+        while (abs(m - mold) > tol and np.linalg.norm(y_final - y_old) > tol):
+            mold = m
+            y_old = y_final
+            y_final = D.dot(y_final)
+            m = np.max(y_final)
+            y_final = y_final / m
+        self.Xinit = np.sqrt(m) * y_final / np.linalg.norm(y_final) * nrm
+
+    def forward_model(self, w):
+        w = w.double().cpu().numpy() if self._is_dev(w) else w
+        return np.absolute(self.A.dot(w))
+
+    def f(self, w):
+        return np.linalg.norm(self.Y - self.forward_model(w)) ** 2 / 2 / self.M
+
+    def _grad(self, z, rows, scale):
+        zd = (z if self._is_dev(z) else self.to_device(z)).reshape(-1)
+        if self._ws is None:
+            from . import _native as N
+            self._ws = torch.empty(N.lib().pnp_pr_workspace_elems(self.M, self.N), dtype=self.dtype, device=self.device)
+        g = ops.pr_grad(self._A_d, zd, self._Y_d, rows=rows, scale=scale, workspace=self._ws)
+        return self._ret(g, z)
+
+    def grad_full(self, z):
+        return self._grad(z, None, 1.0 / self.M)
+
+    def grad_stoch(self, z, mb, *, scale=1.0):
+        rows = torch.from_numpy(np.flatnonzero(np.asarray(mb)).astype(np.int32)).to(self.device)
+        return self._grad(z, rows, scale)

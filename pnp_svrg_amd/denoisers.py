@@ -14,6 +14,7 @@ from . import ops
 def _as_dev(noisy, dtype=None):
     if isinstance(noisy, torch.Tensor):
         return noisy
+    ops.require_gpu()                      # fail loudly (NativeError) when there is no MI355X / no library
     from .problems import get_default_dtype
     return torch.from_numpy(np.ascontiguousarray(noisy, dtype=np.float64)).to('cuda', dtype or get_default_dtype())
 

@@ -1,0 +1,173 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/pnp_hip.h declares
+(no compute without a GPU), the product fails loudly without a GPU (no CPU fallback), host-side
+logic (sharding, BN folding, weight import), and the world_size-2 gloo path of the sweep."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib_path():
+    from pnp_svrg_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _native.LIB_PATH
+
+
+def test_header_symbols_exported():
+    from pnp_svrg_amd import _native
+    hdr = open(os.path.join(ROOT, 'include', 'pnp_hip.h')).read()
+    declared = set(re.findall(r'\b(pnp_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    h = ctypes.CDLL(_lib_path())
+    missing = [n for n in declared if not hasattr(h, n)]
+    assert not missing, missing
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    h.pnp_version.restype = ctypes.c_int
+    assert h.pnp_version() >= 100
+
+
+def test_argument_errors_are_reported_without_gpu():
+    from pnp_svrg_amd import _native as N
+    lib = N.lib()
+    h = ctypes.c_void_p()
+    assert lib.pnp_csmri_plan_create(ctypes.byref(h), 100, 100, 1, 0) == 1          # unsupported size -> PNP_ERR_ARG
+    assert b'supported sizes' in lib.pnp_last_error()
+    with pytest.raises(N.NativeError):
+        N.call('pnp_sigma_est', None, 256, 256, 1, 0, None, None)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU behaviour')
+def test_no_cpu_fallback():
+    import problems
+    import denoisers
+    from pnp_svrg_amd import _native as N
+    with pytest.raises(N.NativeError):
+        problems.CSMRI(os.path.join(ROOT, 'tests', 'golden', 'synth64.png'), 64, 64, 0.2, snr=20.)
+    with pytest.raises(N.NativeError):
+        denoisers.TVDenoiser().denoise(noisy=np.zeros((64, 64)), sigma_est=0.1)
+
+
+def test_product_does_not_import_oracle():
+    for d in ('pnp_svrg_amd', 'algorithms', 'problems', 'denoisers'):
+        for dp, _, fs in os.walk(os.path.join(ROOT, d)):
+            for f in fs:
+                if f.endswith('.py'):
+                    src = open(os.path.join(dp, f)).read()
+                    assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), os.path.join(dp, f)
+
+
+def test_dropin_import_surface():
+    import algorithms, problems, denoisers
+    for n in ('pnp_gd', 'pnp_sgd', 'pnp_svrg', 'pnp_saga', 'pnp_sarah', 'tune_pnp_gd', 'tune_pnp_sgd', 'tune_pnp_svrg',
+              'tune_pnp_saga', 'tune_pnp_sarah'):
+        assert callable(getattr(algorithms, n))
+    for n in ('Problem', 'CSMRI', 'Deblur', 'PhaseRetrieval'):
+        assert hasattr(problems, n)
+    for n in ('Denoise', 'BM3DDenoiser', 'RealSN_DnCNNDenoiser', 'NLMDenoiser', 'TVDenoiser'):
+        assert hasattr(denoisers, n)
+    # flat-import style of the reference (its __init__ appends the package dir to sys.path)
+    from CSMRI import CSMRI
+    from TV import TVDenoiser
+    from pnp_svrg import pnp_svrg
+    assert CSMRI is problems.CSMRI and TVDenoiser is denoisers.TVDenoiser and pnp_svrg is algorithms.pnp_svrg
+    import inspect
+    sig = inspect.signature(algorithms.pnp_svrg)
+    assert list(sig.parameters)[:10] == ['problem', 'denoiser', 'eta', 'tt', 'T2', 'mini_batch_size', 'verbose',
+                                         'lr_decay', 'converge_check', 'diverge_check']
+    assert list(inspect.signature(algorithms.pnp_saga).parameters)[:6] == ['problem', 'denoiser', 'eta', 'tt', 'mini_batch_size', 'hist_size']
+
+
+def test_weight_import_and_bn_fold():
+    from conftest import golden
+    from pnp_svrg_amd.denoisers import dncnn_weights_from_state_dict, random_dncnn_weights
+    g = dict(golden('dncnn_noise15.npz'))
+    # rebuild a reference-style state dict (module. prefix, Sequential indices) and re-import it
+    sd, ci = {}, 0
+    for i in range(17):
+        sd[f'module.dncnn.{ci}.weight'] = torch.from_numpy(g[f'conv{i}.weight'])
+        if f'bn{i}.weight' in g:
+            sd[f'module.dncnn.{ci + 1}.weight'] = torch.from_numpy(g[f'bn{i}.weight'])
+            sd[f'module.dncnn.{ci + 1}.bias'] = torch.from_numpy(g[f'bn{i}.bias'])
+            sd[f'module.dncnn.{ci + 1}.running_mean'] = torch.from_numpy(g[f'bn{i}.mean'])
+            sd[f'module.dncnn.{ci + 1}.running_var'] = torch.from_numpy(g[f'bn{i}.var'])
+            sd[f'module.dncnn.{ci + 1}.num_batches_tracked'] = torch.tensor(0)
+            ci += 3
+        else:
+            ci += 2
+    w = dncnn_weights_from_state_dict(sd)
+    assert int(w['n_layers']) == 17 and all(np.array_equal(w[k], g[k]) for k in g)
+    # RealSN layout: weight_orig / weight_u are ignored, `weight` is used
+    sd2 = {'dncnn.0.weight_orig': torch.zeros(64, 1, 3, 3), 'dncnn.0.weight': torch.ones(64, 1, 3, 3),
+           'dncnn.0.weight_u': torch.zeros(1, 64, 40, 40), 'dncnn.2.weight': torch.ones(1, 64, 3, 3)}
+    w2 = dncnn_weights_from_state_dict(sd2)
+    assert int(w2['n_layers']) == 2 and w2['conv0.weight'].sum() == 64 * 9
+    r = random_dncnn_weights(17)
+    assert r['conv0.weight'].shape == (64, 1, 3, 3) and r['conv16.weight'].shape == (1, 64, 3, 3) and 'bn1.var' in r
+
+
+def test_shard_covers_items_once():
+    from pnp_svrg_amd import sweep
+    items = sweep.make_items(12, [0.1 * k for k in range(1, 11)], [20.0])
+    assert len(items) == 120                                    # Set12 x 10 sampling ratios
+    for world in (1, 2, 4, 8):
+        parts = [sweep.shard(items, r, world) for r in range(world)]
+        ids = sorted(i['id'] for p in parts for i in p)
+        assert ids == list(range(120))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    out = sweep.run_sweep(items, lambda mine: [{'id': it['id'], 'v': it['alpha'] * 2} for it in mine])
+    assert [r['id'] for r in out] == list(range(120))
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from pnp_svrg_amd import sweep
+dist.init_process_group('gloo')
+items = sweep.make_items(3, [0.1, 0.2, 0.3], [10.0, 20.0])
+def runner(mine):
+    return [{'id': it['id'], 'rank': dist.get_rank(), 'val': it['image'] * 100 + it['alpha'] + it['snr']} for it in mine]
+res = sweep.run_sweep(items, runner)
+if dist.get_rank() == 0:
+    assert [r['id'] for r in res] == list(range(18)), res
+    assert {r['rank'] for r in res} == {0, 1}
+    assert all(r['rank'] == r['id'] % 2 for r in res)
+    print('SWEEP_OK', len(res))
+else:
+    assert res is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sweep_gloo_world2(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), ROOT],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert 'SWEEP_OK 18' in out.stdout
+
+
+def test_sweep_csv(tmp_path):
+    from pnp_svrg_amd import sweep
+    items = sweep.make_items(2, [0.2], [20.0])
+    res = [{'id': it['id'], 'item': it, 'loss': -1.5} for it in items]
+    p = tmp_path / 'out' / 'r.csv'
+    sweep.write_csv(str(p), res, denoiser='DnCNN')
+    rows = p.read_text().strip().splitlines()
+    assert rows[0] == 'Problem,Denoiser,Algorithm,Alpha,SNR,Loss,PARAMETERS' and len(rows) == 3

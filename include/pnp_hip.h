@@ -148,6 +148,9 @@ int pnp_dncnn_denoise(pnp_dncnn_plan* plan, const void* z_in, void* z_out, int d
  * stream (no synchronisation until _end).  _end returns the mean duration of one conv launch.  */
 int pnp_dncnn_profile_begin(pnp_dncnn_plan* plan, int max_calls);
 int pnp_dncnn_profile_end(pnp_dncnn_plan* plan, double* avg_ms_per_launch, long* launches);
+/* Diagnostic (allocates + synchronises; never on the hot path): median in-kernel shader cycles and 100 MHz
+ * reference ticks of the conv tile loop after `reps` back-to-back launches -> the clock held under load. */
+int pnp_dncnn_debug_clock(pnp_dncnn_plan* plan, int reps, double* cycles, double* ref_ticks, void* stream);
 
 /* ------------------------------------------------------------------ elementwise
  * out = a*x + b*y + c*w   (y, w may be NULL); n = total element count.

@@ -42,6 +42,7 @@ SIGNATURES = {
     'pnp_dncnn_denoise': (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     'pnp_dncnn_profile_begin': (_i, [_vp, _i]),
     'pnp_dncnn_profile_end': (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(ctypes.c_long)]),
+    'pnp_dncnn_debug_clock': (_i, [_vp, _i, ctypes.POINTER(_d), ctypes.POINTER(_d), _vp]),
     'pnp_axpbypcz': (_i, [_d, _vp, _d, _vp, _d, _vp, _vp, _sz, _i, _vp]),
 }
 

@@ -27,6 +27,8 @@
 //     matrix pipe is the only busy resource by a wide margin.
 #include "common.h"
 #include <vector>
+#include <algorithm>
+#include <cstdlib>
 
 namespace pnp {
 
@@ -42,8 +44,10 @@ constexpr int XOFF = 3;           // LDS column of image column tx0-1
 constexpr int PLANE = PR * PC;    // 400 floats per channel; 400 % 32 == 16 -> the 4 k-rows of a B operand
                                   // (lanes 0-15 / 16-31 of a half-wave) fall on disjoint LDS banks
 constexpr int HALF_C = 32;        // channels per K-half
-constexpr int HALF_LDS = HALF_C * PLANE;              // 12800 floats = 50 KB per LDS buffer
-constexpr int CHUNKS = HALF_LDS / 4;                  // 3200 16-byte chunks = 50 wave-pieces per half
+constexpr int HALF_PAYLOAD = HALF_C * PLANE;          // 12800 floats = 50 KB of halo tile per K-half
+constexpr int HALF_LDS = 52 * 256;                    // LDS buffer rounded up to 13 DMA pieces per wave (52 KB):
+                                                      // every wave issues the same, branch-free piece sequence
+constexpr int CHUNKS = HALF_PAYLOAD / 4;              // 3200 16-byte chunks = 50 wave-pieces per half
 constexpr int KSTEPS_HALF = 9 * (HALF_C / 4);         // 72 MFMA K-steps (K=4 each) per half
 constexpr int MT = 16;                                // 16-pixel M-tiles per output tile (8 rows x 2)
 
@@ -76,12 +80,15 @@ __device__ __forceinline__ void dma_half(const float* __restrict__ in, const flo
     for (int pc = wv; pc < PIECES; pc += 4) dma_piece(pc, in, zeros, ldsbuf, H, W, b, ty0, tx0, half, lane, valid_tile);
 }
 
-template <bool RELU>
+// STAMP / ABL: diagnostic builds only (pnp_dncnn_debug_clock): s_memtime / s_memrealtime around the tile
+// loop and its phases; ABL bit 0 replaces the LDS reads by register values, bit 1 drops the DMA.
+template <bool RELU, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, float* __restrict__ out,
                                                 const float* __restrict__ wpack, const float* __restrict__ bias,
-                                                const float* __restrict__ zeros, int H, int W, int ntiles) {
+                                                const float* __restrict__ zeros, int H, int W, int ntiles,
+                                                unsigned long long* __restrict__ stamps = nullptr) {
     __shared__ float lds[2 * HALF_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
 
     // weight slice of this wave (16 couts x 576): wreg[s] = W'[16wv + (lane&15)][k = 4s + (lane>>4)]
@@ -93,6 +100,21 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
     for (int r = 0; r < 4; ++r) bv[r] = bias[16 * wv + 4 * (lane >> 4) + r];
 
     const int lbase = (lane >> 4) * PLANE + (lane & 15) + XOFF;     // lane part of the B-operand LDS address
+    int loff[4];                                               // lane part of the output offsets (per register)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) loff[r] = (16 * wv + 4 * (lane >> 4) + r) * H * W + (lane & 15);
+
+    // Per-lane descriptors of this wave's DMA pieces (tile independent): element offset of the chunk relative
+    // to the tile origin ((b*64 + half*32)*H + ty0 - 1)*W + tx0 - 4, and its (halo row, 4*chunk column).
+    int poff[PIECES_PER_WAVE], pry[PIECES_PER_WAVE], pcx4[PIECES_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PIECES_PER_WAVE; ++i) {
+        const int q = (wv + 4 * i) * 64 + lane;
+        const int cin = q / 100, r = q - cin * 100;
+        pry[i] = r / 10;
+        pcx4[i] = 4 * (r - pry[i] * 10);
+        poff[i] = (cin * H + pry[i]) * W + pcx4[i];
+    }
 
     int tile = blockIdx.x;
     {
@@ -100,6 +122,8 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
         dma_half(in, zeros, lds, H, W, b, (t2 / tiles_x) * TR, (t2 % tiles_x) * TC, 0, tid, tile < ntiles);
     }
     __syncthreads();                                        // (drains the DMA: vmcnt(0) + barrier)
+    unsigned long long t0 = 0, r0 = 0, acc_compute = 0, acc_barrier = 0, acc_epi = 0, tp = 0;
+    if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
@@ -117,8 +141,14 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
             const int n2 = nt - nb * tiles_per_img;
             const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
             const bool nvalid = half == 0 ? true : nt < ntiles;
+            const float* nsrc0 = in + (((size_t)nb * C + (half ^ 1) * HALF_C) * H + nty0 - 1) * (size_t)W + ntx0 - 4;
 
-            const float* xb = lds + half * HALF_LDS + lbase;
+            // keep the buffer base in a register of its own: every B-operand address is then base +
+            // a 16-bit immediate (< 48 KB) instead of one v_add per LDS read
+            int xb_off = half * HALF_LDS + lbase;
+            asm volatile("" : "+v"(xb_off));
+            const float* xb = lds + xb_off;
+            if (STAMP) tp = __builtin_amdgcn_s_memtime();
             // B operands of one (channel quad c4, dx) group: the 10 halo rows x 2 column halves; each
             // value feeds up to three taps (dy): 20 LDS reads per 48 MFMAs.  Software pipeline: the reads
             // of group g+1 and one DMA piece of the next buffer are issued underneath the MFMAs of group g.
@@ -127,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
 #pragma unroll
             for (int ry = 0; ry < PR; ++ry)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) xr[0][ry][h] = xb[ry * PC + 16 * h];
+                for (int h = 0; h < 2; ++h) xr[0][ry][h] = (ABL & 1) ? (float)(lane + ry + h) : xb[ry * PC + 16 * h];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int c4 = g / 3, dx = g % 3;
@@ -136,11 +166,18 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
 #pragma unroll
                     for (int ry = 0; ry < PR; ++ry)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) xr[(g + 1) & 1][ry][h] = xb[(4 * c4n) * PLANE + ry * PC + 16 * h + dxn];
+                        for (int h = 0; h < 2; ++h)
+                            xr[(g + 1) & 1][ry][h] = (ABL & 1) ? xr[g & 1][ry][h] : xb[(4 * c4n) * PLANE + ry * PC + 16 * h + dxn];
                 }
-                if (g < PIECES_PER_WAVE) {
+                if (g < PIECES_PER_WAVE && !(ABL & 2)) {
+                    // branch-free and identical in every wave (a branch here would split the MFMA scheduling
+                    // region): pieces 50/51 and the pieces of a non-existent next tile just move zeros
                     const int pc = wv + 4 * g;
-                    if (pc < PIECES) dma_piece(pc, in, zeros, nbuf, H, W, nb, nty0, ntx0, half ^ 1, lane, nvalid);
+                    const int y = nty0 - 1 + pry[g], x = ntx0 - 4 + pcx4[g];
+                    const bool ok = nvalid & (pc < PIECES) & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
+                    const float* src = ok ? nsrc0 + poff[g] : zeros;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(nbuf + pc * 256), 16, 0, 0);
                 }
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
@@ -158,21 +195,34 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_compute += t - tp; tp = t; }
             __syncthreads();                                // next buffer landed (vmcnt(0)) + everyone done reading
+            if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_barrier += t - tp; tp = t; }
         }
 
-        // epilogue: bias (+ReLU); each accumulator register = 16 adjacent pixels of one channel
+        // epilogue: bias (+ReLU); each accumulator register = 16 adjacent pixels of one channel.
+        // 32-bit in-image offsets off a per-tile scalar base: one v_add per store, no 64-bit multiplies.
+        // (The transposed operand order -- 4 adjacent pixels per lane, one float4 store per M-tile -- was
+        // measured SLOWER: each store instruction then touches 16 channel planes instead of 4.)
+        float* ob = out + (size_t)b * C * H * W + ty0 * W + tx0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int y = ty0 + (m >> 1), x = tx0 + 16 * (m & 1) + (lane & 15);
+            const int so = (m >> 1) * W + 16 * (m & 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int cout = 16 * wv + 4 * (lane >> 4) + r;
                 float v = acc[m][r] + bv[r];
                 if (RELU) v = v > 0.f ? v : 0.f;
-                out[(((size_t)b * C + cout) * H + y) * W + x] = v;
+                ob[loff[r] + so] = v;
             }
         }
+        if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_epi += t - tp; }
+    }
+    if (STAMP && tid == 0) {
+        stamps[5 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+        stamps[5 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+        stamps[5 * blockIdx.x + 2] = acc_compute;
+        stamps[5 * blockIdx.x + 3] = acc_barrier;
+        stamps[5 * blockIdx.x + 4] = acc_epi;
     }
 }
 
@@ -468,6 +518,42 @@ extern "C" int pnp_dncnn_profile_end(pnp_dncnn_plan* p, double* avg_ms_per_launc
     }
     *launches = p->prof_launches;
     *avg_ms_per_launch = p->prof_launches ? p->prof_ms / (double)p->prof_launches : 0.0;
+    return PNP_OK;
+}
+
+// Diagnostic: in-kernel shader clock and phase shares of the conv kernel under load.  Runs `reps` back-to-back
+// conv launches on the plan's activation buffers (contents arbitrary), the last one stamped; returns the median
+// over workgroups of (shader cycles, 100 MHz reference ticks) spent in the tile loop.  PNP_DEBUG_STAMPS=1 prints
+// the compute / barrier / epilogue split, PNP_DEBUG_ABL selects an ablation build.
+extern "C" int pnp_dncnn_debug_clock(pnp_dncnn_plan* p, int reps, double* cycles, double* ref_ticks, void* stream) {
+    PNP_CHECK_ARG(p && cycles && ref_ticks && reps >= 1, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int ntiles = p->batch * (p->H / TR) * (p->W / TC);
+    const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
+    unsigned long long* d = nullptr;
+    PNP_CHECK_HIP(hipMalloc(&d, (size_t)grid * 5 * sizeof(unsigned long long)));
+    for (int i = 0; i < reps - 1; ++i)
+        k_mid<true><<<grid, 256, 0, s>>>(p->act0, p->act1, p->wpack, p->bias, p->zeros, p->H, p->W, ntiles);
+    const char* abl = getenv("PNP_DEBUG_ABL");
+    const int ab = abl ? atoi(abl) : 0;
+    if (ab == 2) k_mid<true, true, 2><<<grid, 256, 0, s>>>(p->act0, p->act1, p->wpack, p->bias, p->zeros, p->H, p->W, ntiles, d);
+    else k_mid<true, true><<<grid, 256, 0, s>>>(p->act0, p->act1, p->wpack, p->bias, p->zeros, p->H, p->W, ntiles, d);
+    std::vector<unsigned long long> h((size_t)grid * 5);
+    hipError_t e = hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    PNP_CHECK_HIP(e);
+    std::vector<double> c(grid), r(grid);
+    for (int i = 0; i < grid; ++i) { c[i] = (double)h[5 * i]; r[i] = (double)h[5 * i + 1]; }
+    if (getenv("PNP_DEBUG_STAMPS")) {
+        double a = 0, b = 0, ep = 0;
+        for (int i = 0; i < grid; ++i) { a += h[5 * i + 2]; b += h[5 * i + 3]; ep += h[5 * i + 4]; }
+        fprintf(stderr, "[k_mid stamps] mean cycles per WG: compute %.0f  barrier %.0f  epilogue %.0f\n", a / grid, b / grid, ep / grid);
+    }
+    std::sort(c.begin(), c.end());
+    std::sort(r.begin(), r.end());
+    *cycles = c[grid / 2];
+    *ref_ticks = r[grid / 2];
     return PNP_OK;
 }
 

@@ -147,11 +147,18 @@ def main():
                 traffic = json.load(open(tj)).get(f'k_mid_B{B}')
             except Exception:
                 traffic = None
-        roofline = {'bound': 'mfma', 'kernel': 'pnp::k_mid (64->64 3x3 conv, v_mfma_f32_16x16x4_f32)',
+        wino = os.environ.get('PNP_DNCNN_WINOGRAD', '1') != '0'
+        roofline = {'bound': 'mfma',
+                    'kernel': ('pnp::k_mid_wino (64->64 3x3 conv, Winograd F(2,3) along x on v_mfma_f32_16x16x4_f32: 2/3 of the '
+                               'direct form\'s multiply-adds, so the ALGORITHMIC rate can exceed the matrix-core peak)') if wino
+                              else 'pnp::k_mid (64->64 3x3 conv, direct implicit GEMM on v_mfma_f32_16x16x4_f32)',
                     'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                     'launch_ms': round(ms, 4), 'launches_timed': launches,
-                    'flops_per_launch': flops}
+                    'flops_per_launch': flops,
+                    # what the matrix cores actually execute (Winograd F(2,3) needs 2/3 of the multiply-adds)
+                    'executed_tflops': round(ach * (2.0 / 3.0 if wino else 1.0), 2),
+                    'executed_frac_of_mfma_peak': round(ach * (2.0 / 3.0 if wino else 1.0) / F32_MFMA_PEAK_TFLOPS, 4)}
 
     # final gather of the results (the only collective on this path; outside the timed region)
     trace = eng.psnr_trace()

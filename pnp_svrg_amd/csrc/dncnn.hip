@@ -226,6 +226,158 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
     }
 }
 
+// ------------------------------------------------------------------------------- Winograd F(2,3) variant
+// Same tile / LDS image / DMA pipeline as k_mid, but the 3 horizontal taps go through the 1-D Winograd
+// minimal-filtering transform F(2,3): per output PAIR (x, x+1) and input row,
+//     V = B^T d  (d = inputs x-1 .. x+2):  V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3
+//     U = G g    (g = the 3 horizontal weights): U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2
+//     m_xi = sum_{dy,cin} U_xi V_xi ;   y(x) = m0 + m1 + m2 ,  y(x+1) = m1 - m2 - m3
+// i.e. 4 x 3 x 64 multiply-adds per output pair instead of 2 x 9 x 64: 2/3 of the matrix-core work of the
+// direct form for the same (exact-arithmetic) result; fp32 throughout, rounding differs from the fmaf chain
+// at the 1e-7 level.  An M-tile is the 16 pixel pairs of one 32-pixel output row; a wave keeps
+// 8 rows x 4 xi accumulators (128 regs) and its 4 x 3 x 16 = 192 transformed weights in registers.
+// The B-operand transform (4 LDS values -> 4 V values, 4 VALU ops) feeds up to 12 MFMAs.
+constexpr int WINO_U = 2 * (HALF_C / 4) * 3 * 4;      // 192 transformed-weight registers per wave
+
+template <bool RELU, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ in, float* __restrict__ out,
+                                                     const float* __restrict__ upack, const float* __restrict__ bias,
+                                                     const float* __restrict__ zeros, int H, int W, int ntiles,
+                                                     unsigned long long* __restrict__ stamps = nullptr) {
+    __shared__ float lds[2 * HALF_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
+
+    // ureg[((half*8 + c4)*3 + dy)*4 + xi] = U_xi[cout = 16wv + (lane&15)][cin = 32half + 4c4 + (lane>>4)][dy]
+    float ureg[WINO_U];
+#pragma unroll
+    for (int s = 0; s < WINO_U; ++s) ureg[s] = upack[((size_t)wv * WINO_U + s) * 64 + lane];
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[16 * wv + 4 * (lane >> 4) + r];
+
+    // lane (k-row kq = lane>>4, pair j = lane&15) reads d0..d3 at LDS columns XOFF + 2j + {0,1,2,3}
+    const int lbase = (lane >> 4) * PLANE + 2 * (lane & 15) + XOFF;
+    int loff[4];                                               // output offsets: pixel pair 2j of channel ...
+#pragma unroll
+    for (int r = 0; r < 4; ++r) loff[r] = (16 * wv + 4 * (lane >> 4) + r) * H * W + 2 * (lane & 15);
+
+    int poff[PIECES_PER_WAVE], prc[PIECES_PER_WAVE];           // DMA piece descriptors (see k_mid)
+#pragma unroll
+    for (int i = 0; i < PIECES_PER_WAVE; ++i) {
+        const int q = (wv + 4 * i) * 64 + lane;
+        const int cin = q / 100, r = q - cin * 100;
+        const int ry = r / 10, cx4 = 4 * (r - ry * 10);
+        prc[i] = ry | (cx4 << 8);
+        poff[i] = (cin * H + ry) * W + cx4;
+    }
+
+    int tile = blockIdx.x;
+    {
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        dma_half(in, zeros, lds, H, W, b, (t2 / tiles_x) * TR, (t2 % tiles_x) * TC, 0, tid, tile < ntiles);
+    }
+    __syncthreads();
+    unsigned long long t0 = 0, r0 = 0;
+    if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
+        f32x4 acc[TR][4];
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) acc[r][xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float* nbuf = lds + (half ^ 1) * HALF_LDS;
+            const int nt = tile + gridDim.x;
+            const int nb = half == 0 ? b : nt / tiles_per_img;
+            const int n2 = nt - nb * tiles_per_img;
+            const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
+            const bool nvalid = half == 0 ? true : nt < ntiles;
+            const float* nsrc0 = in + (((size_t)nb * C + (half ^ 1) * HALF_C) * H + nty0 - 1) * (size_t)W + ntx0 - 4;
+
+            int xb_off = half * HALF_LDS + lbase;
+            asm volatile("" : "+v"(xb_off));
+            const float* xb = lds + xb_off;
+
+            // group = (channel quad c4, block of 5 halo rows): 10 ds_read2 + 20 transform ops + 48 MFMAs
+            constexpr int NG = (HALF_C / 4) * 2;               // 16 groups per half
+            float d[2][5][4];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d[0][i][t] = xb[i * PC + t];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int c4 = g / 2, rb = g % 2;
+                if (g + 1 < NG) {
+                    const int c4n = (g + 1) / 2, rbn = (g + 1) % 2;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) d[(g + 1) & 1][i][t] = xb[(4 * c4n) * PLANE + (5 * rbn + i) * PC + t];
+                }
+                if (g < PIECES_PER_WAVE) {
+                    const int pc = wv + 4 * g;
+                    const int y = nty0 - 1 + (prc[g] & 255), x = ntx0 - 4 + (prc[g] >> 8);
+                    const bool ok = nvalid & (pc < PIECES) & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
+                    const float* src = ok ? nsrc0 + poff[g] : zeros;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(nbuf + pc * 256), 16, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int ry = 5 * rb + i;
+                    const float d0 = d[g & 1][i][0], d1 = d[g & 1][i][1], d2 = d[g & 1][i][2], d3 = d[g & 1][i][3];
+                    const float V[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int r = ry - dy;
+                        if (r >= 0 && r < TR) {
+#pragma unroll
+                            for (int xi = 0; xi < 4; ++xi)
+                                acc[r][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ureg[((half * (HALF_C / 4) + c4) * 3 + dy) * 4 + xi],
+                                                                                   V[xi], acc[r][xi], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+
+        // epilogue: inverse transform, bias (+ReLU); a lane holds pixel pair (2j, 2j+1) of 4 channels per row
+        float* ob = out + (size_t)b * C * H * W + ty0 * W + tx0;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float m0 = acc[r][0][q], m1 = acc[r][1][q], m2 = acc[r][2][q], m3 = acc[r][3][q];
+                float2 v;
+                v.x = (m0 + m1 + m2) + bv[q];
+                v.y = (m1 - m2 - m3) + bv[q];
+                if (RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; }
+                *reinterpret_cast<float2*>(ob + loff[q] + r * W) = v;
+            }
+        }
+    }
+    if (STAMP && tid == 0) {
+        stamps[5 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+        stamps[5 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+        stamps[5 * blockIdx.x + 2] = stamps[5 * blockIdx.x + 3] = stamps[5 * blockIdx.x + 4] = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------- first layer
 // xt = ((z - lo) / (hi - lo)) * srange + sshift ; act[c] = relu(sum_t w[c][t] * xt[tap t])
 template <typename T>
@@ -381,7 +533,8 @@ using namespace pnp;
 
 struct pnp_dncnn_plan {
     int n_mid, H, W, batch, num_cu;
-    float *w_first, *w_last, *wpack, *bias;      // device
+    float *w_first, *w_last, *wpack, *upack, *bias;   // device (upack: Winograd F(2,3)-transformed weights)
+    int use_wino;
     float *act0, *act1, *zeros;                  // [B][64][H][W] x2; a zero word for halo padding
     double* mm;                                  // [B][2] (as double or float depending on call)
     double* sse_part;                            // [B][H*W/256]
@@ -418,9 +571,28 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
                     pack[(((size_t)l * 4 + wv) * 2 * KSTEPS_HALF + s) * 64 + lane] =
                         w_mid[(((size_t)l * C + cout) * C + cin) * 9 + tap];
                 }
+    // Winograd F(2,3)-transformed weights (along dx): upack[l][wv][s][lane], s = ((half*8 + c4)*3 + dy)*4 + xi
+    std::vector<float> upk((size_t)n_mid * 4 * WINO_U * 64);
+    for (int l = 0; l < n_mid; ++l)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int s = 0; s < WINO_U; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int xi = s % 4, dy = (s / 4) % 3, c4 = (s / 12) % (HALF_C / 4), half = s / (12 * (HALF_C / 4));
+                    const int cout = 16 * wv + (lane & 15), cin = HALF_C * half + 4 * c4 + (lane >> 4);
+                    const float* g = w_mid + (((size_t)l * C + cout) * C + cin) * 9 + dy * 3;
+                    const double g0 = g[0], g1 = g[1], g2 = g[2];
+                    const double u = xi == 0 ? g0 : xi == 1 ? 0.5 * (g0 + g1 + g2) : xi == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+                    upk[(((size_t)l * 4 + wv) * WINO_U + s) * 64 + lane] = (float)u;
+                }
+    {
+        const char* ev = getenv("PNP_DNCNN_WINOGRAD");
+        p->use_wino = ev ? atoi(ev) : 1;
+    }
     const size_t act_bytes = (size_t)batch * C * H * W * sizeof(float);
     hipError_t e = hipMalloc(&p->wpack, pack.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->wpack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->upack, upk.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->upack, upk.data(), upk.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->bias, (size_t)n_mid * C * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->bias, b_mid, (size_t)n_mid * C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->w_first, C * 9 * sizeof(float));
@@ -435,7 +607,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e == hipSuccess) e = hipMalloc(&p->sse_part, (size_t)batch * (H * W / 256) * sizeof(double));
     if (e != hipSuccess) {
         set_error(std::string("pnp_dncnn_plan_create: ") + hipGetErrorString(e));
-        for (void* q : {(void*)p->wpack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
+        for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
                         (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part})
             if (q) (void)hipFree(q);
         delete p;
@@ -447,7 +619,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
 
 extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
     if (!p) return PNP_OK;
-    for (void* q : {(void*)p->wpack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
+    for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
                     (void*)p->zeros, (void*)p->mm, (void*)p->sse_part})
         (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -477,8 +649,12 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     const bool prof = p->profile && p->ev_used + 2 <= p->ev.size();
     if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
     for (int l = 0; l < p->n_mid; ++l) {
-        k_mid<true><<<grid, 256, 0, s>>>(src, dst, p->wpack + (size_t)l * 4 * 2 * KSTEPS_HALF * 64, p->bias + (size_t)l * C,
-                                         p->zeros, H, W, ntiles);
+        if (p->use_wino)
+            k_mid_wino<true><<<grid, 256, 0, s>>>(src, dst, p->upack + (size_t)l * 4 * WINO_U * 64, p->bias + (size_t)l * C,
+                                                  p->zeros, H, W, ntiles);
+        else
+            k_mid<true><<<grid, 256, 0, s>>>(src, dst, p->wpack + (size_t)l * 4 * 2 * KSTEPS_HALF * 64, p->bias + (size_t)l * C,
+                                             p->zeros, H, W, ntiles);
         PNP_CHECK_LAUNCH();
         float* t = src; src = dst; dst = t;
     }

@@ -80,9 +80,14 @@ class DncnnPlan:
     bn{i}.{weight,bias,mean,var} for the middle layers -- exactly what tests/golden/dncnn_noise15.npz
     holds or what `load_dncnn_state_dict` extracts from a reference .pth.  BatchNorm (eval) is folded here."""
 
-    def __init__(self, weights, H, W, batch):
+    def __init__(self, weights, H, W, batch, winograd=None):
+        """winograd: True = F(2,3) conv kernel (default; fp32, 2/3 of the matrix-core work),
+        False = direct implicit GEMM (bit-for-bit an fmaf chain), None = env PNP_DNCNN_WINOGRAD or True."""
         import numpy as np
+        import os
         require_gpu()
+        if winograd is not None:
+            os.environ['PNP_DNCNN_WINOGRAD'] = '1' if winograd else '0'
         n = int(weights['n_layers'])
         self.H, self.W, self.B, self.n_mid = H, W, batch, n - 2
         w_first = np.ascontiguousarray(weights['conv0.weight'], dtype=np.float32).reshape(64, 9)

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
 // 8 rows x 4 xi accumulators (128 regs) and its 4 x 3 x 16 = 192 transformed weights in registers.
 // The B-operand transform (4 LDS values -> 4 V values, 4 VALU ops) feeds up to 12 MFMAs.
 constexpr int WINO_U = 2 * (HALF_C / 4) * 3 * 4;      // 192 transformed-weight registers per wave
+struct __attribute__((packed, aligned(4))) f2u { float a, b; };   // 4-byte-aligned float pair
 
 template <bool RELU, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ in, float* __restrict__ out,
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
         dma_half(in, zeros, lds, H, W, b, (t2 / tiles_x) * TR, (t2 % tiles_x) * TC, 0, tid, tile < ntiles);
     }
     __syncthreads();
-    unsigned long long t0 = 0, r0 = 0;
+    unsigned long long t0 = 0, r0 = 0, acc_compute = 0, acc_barrier = 0, acc_epi = 0, tp = 0;
     if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
     for (; tile < ntiles; tile += gridDim.x) {
@@ -303,23 +304,29 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
             int xb_off = half * HALF_LDS + lbase;
             asm volatile("" : "+v"(xb_off));
             const float* xb = lds + xb_off;
+            if (STAMP) tp = __builtin_amdgcn_s_memtime();
 
             // group = (channel quad c4, block of 5 halo rows): 10 ds_read2 + 20 transform ops + 48 MFMAs
             constexpr int NG = (HALF_C / 4) * 2;               // 16 groups per half
             float d[2][5][4];
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) d[0][i][t] = xb[i * PC + t];
+            for (int i = 0; i < 5; ++i) {
+                // two 4-byte-aligned pair loads (d0,d1), (d2,d3): one ds_read2_b32 each off ONE base register
+                const f2u lo = *reinterpret_cast<const f2u*>(xb + i * PC), hi = *reinterpret_cast<const f2u*>(xb + i * PC + 2);
+                d[0][i][0] = lo.a; d[0][i][1] = lo.b; d[0][i][2] = hi.a; d[0][i][3] = hi.b;
+            }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int c4 = g / 2, rb = g % 2;
                 if (g + 1 < NG) {
                     const int c4n = (g + 1) / 2, rbn = (g + 1) % 2;
+                    // one base per group (a plane is 400 dwords, ds_read2 offsets reach 255): 1 v_add, 10 ds_read2
+                    const float* gb = xb + (4 * c4n) * PLANE + (5 * rbn) * PC;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) d[(g + 1) & 1][i][t] = xb[(4 * c4n) * PLANE + (5 * rbn + i) * PC + t];
+                    for (int i = 0; i < 5; ++i) {
+                        const f2u lo = *reinterpret_cast<const f2u*>(gb + i * PC), hi = *reinterpret_cast<const f2u*>(gb + i * PC + 2);
+                        d[(g + 1) & 1][i][0] = lo.a; d[(g + 1) & 1][i][1] = lo.b; d[(g + 1) & 1][i][2] = hi.a; d[(g + 1) & 1][i][3] = hi.b;
+                    }
                 }
                 if (g < PIECES_PER_WAVE) {
                     const int pc = wv + 4 * g;
@@ -353,7 +360,9 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_compute += t - tp; tp = t; }
             __syncthreads();
+            if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_barrier += t - tp; tp = t; }
         }
 
         // epilogue: inverse transform, bias (+ReLU); a lane holds pixel pair (2j, 2j+1) of 4 channels per row
@@ -370,11 +379,14 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                 *reinterpret_cast<float2*>(ob + loff[q] + r * W) = v;
             }
         }
+        if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_epi += t - tp; }
     }
     if (STAMP && tid == 0) {
         stamps[5 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
         stamps[5 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
-        stamps[5 * blockIdx.x + 2] = stamps[5 * blockIdx.x + 3] = stamps[5 * blockIdx.x + 4] = 0;
+        stamps[5 * blockIdx.x + 2] = acc_compute;
+        stamps[5 * blockIdx.x + 3] = acc_barrier;
+        stamps[5 * blockIdx.x + 4] = acc_epi;
     }
 }
 
@@ -708,11 +720,14 @@ extern "C" int pnp_dncnn_debug_clock(pnp_dncnn_plan* p, int reps, double* cycles
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
     unsigned long long* d = nullptr;
     PNP_CHECK_HIP(hipMalloc(&d, (size_t)grid * 5 * sizeof(unsigned long long)));
-    for (int i = 0; i < reps - 1; ++i)
-        k_mid<true><<<grid, 256, 0, s>>>(p->act0, p->act1, p->wpack, p->bias, p->zeros, p->H, p->W, ntiles);
+    for (int i = 0; i < reps - 1; ++i) {
+        if (p->use_wino) k_mid_wino<true><<<grid, 256, 0, s>>>(p->act0, p->act1, p->upack, p->bias, p->zeros, p->H, p->W, ntiles);
+        else k_mid<true><<<grid, 256, 0, s>>>(p->act0, p->act1, p->wpack, p->bias, p->zeros, p->H, p->W, ntiles);
+    }
     const char* abl = getenv("PNP_DEBUG_ABL");
     const int ab = abl ? atoi(abl) : 0;
-    if (ab == 2) k_mid<true, true, 2><<<grid, 256, 0, s>>>(p->act0, p->act1, p->wpack, p->bias, p->zeros, p->H, p->W, ntiles, d);
+    if (p->use_wino) k_mid_wino<true, true><<<grid, 256, 0, s>>>(p->act0, p->act1, p->upack, p->bias, p->zeros, p->H, p->W, ntiles, d);
+    else if (ab == 2) k_mid<true, true, 2><<<grid, 256, 0, s>>>(p->act0, p->act1, p->wpack, p->bias, p->zeros, p->H, p->W, ntiles, d);
     else k_mid<true, true><<<grid, 256, 0, s>>>(p->act0, p->act1, p->wpack, p->bias, p->zeros, p->H, p->W, ntiles, d);
     std::vector<unsigned long long> h((size_t)grid * 5);
     hipError_t e = hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);

@@ -7,8 +7,8 @@
 One "step" = one inner iteration of pnp_svrg (reference algorithms/pnp_svrg.py:41-94: minibatch
 SVRG direction via the masked-FFT gradient, step, estimate_sigma, DnCNN prox, PSNR error sum) for a
 batch of B independent reconstructions per GPU, including the outer full-gradient refresh every
-T2 = 10 steps.  Inputs (problems, network weights, pre-drawn minibatch index lists) are resident
-in HBM before the timed region.  Every rank runs its own B problems (weak scaling; the only
+T2 = 10 steps.  Inputs (problems, network weights) are resident in HBM before the timed region; minibatches are drawn
+on the device inside each step.  Every rank runs its own B problems (weak scaling; the only
 collective is the final gather of results, after the timed region).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel =
@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=16, help='independent reconstructions per GPU')
     ap.add_argument('--workload', default='dncnn', choices=['dncnn', 'tv'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
     return ap.parse_args()
 
 
@@ -110,9 +111,11 @@ def main():
     wdesc = 'reference DnCNN_noise15 weights' if os.path.exists(wfile) else 'random-init weights'
     batch = CsmriBatch.synthetic(B, H, W, SAMPLE_PROB, SNR, seed=100 + rank)
     prox = DnCNNProx(weights, NET_SIGMA) if a.workload == 'dncnn' else TVProx()
-    eng = SvrgEngine(batch, prox, ETA, T2, MB, variant='svrg')
+    eng = SvrgEngine(batch, prox, ETA, T2, MB, variant='svrg', seed=1 + rank)
+    # minibatches are drawn ON THE DEVICE inside every step (pnp_csmri_draw_minibatch), like the reference
+    # draws them inside its timed gradient phase (pnp_svrg.py:52); --host-minibatches pre-draws index lists
     n_draw = min(a.steps + a.warmup, 64)
-    idx = batch.draw_minibatches(n_draw, MB, seed=1 + rank)          # resident in HBM before timing
+    idx = batch.draw_minibatches(n_draw, MB, seed=1 + rank) if a.host_minibatches else None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -121,13 +124,13 @@ def main():
             torch.cuda.synchronize()
 
     for s in range(a.warmup):
-        eng.step(idx[s % n_draw])
+        eng.step(idx[s % n_draw] if idx is not None else None)
     sync_all()
     if a.workload == 'dncnn':
         prox.plan.profile_begin(a.steps + 8)
     t0 = time.perf_counter()
     for s in range(a.steps):
-        eng.step(idx[(a.warmup + s) % n_draw])
+        eng.step(idx[(a.warmup + s) % n_draw] if idx is not None else None)
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -43,6 +43,12 @@ int pnp_csmri_plan_destroy(pnp_csmri_plan* plan);
  * np.flatnonzero(mask) / problems/CSMRI.py:66-74 produce them.  idx: [batch][n] int32,
  * selT: [batch][W][H] uint8 (TRANSPOSED: the column pass reads along ky).              */
 int pnp_csmri_sel_from_indices(pnp_csmri_plan* plan, const int32_t* idx, int n, uint8_t* selT, void* stream);
+/* Device-side minibatch draw (problems/CSMRI.py:66-74 semantics: `mb` of the M0 sampled locations, uniform
+ * without replacement) straight into the transposed selector: counter-based keys hash(seed, step, problem,
+ * position), the mb smallest win (radix select).  mask_idx: [batch][M0] int32 = flatnonzero(mask) per problem.
+ * Deterministic in (seed, step); NOT NumPy's legacy stream (reference-identical draws come from the host). */
+int pnp_csmri_draw_minibatch(pnp_csmri_plan* plan, const int32_t* mask_idx, int M0, int mb, uint64_t seed,
+                             uint32_t step, uint8_t* selT, void* stream);
 /* Same, from a dense row-major 0/1 indicator [batch][H][W] (uint8).                      */
 int pnp_csmri_sel_from_dense(pnp_csmri_plan* plan, const uint8_t* sel, uint8_t* selT, void* stream);
 

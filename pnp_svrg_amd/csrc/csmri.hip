@@ -221,6 +221,94 @@ __global__ void k_sel_transpose(const uint8_t* __restrict__ sel, uint8_t* __rest
         if (x < H && y + j < W) d[(size_t)(y + j) * H + x] = tile[threadIdx.x][threadIdx.y + j];
 }
 
+// ------------------------------------------------------------------------------- minibatch draw
+// problems/CSMRI.py:66-74 (`np.random.choice(flatnonzero(mask), size, replace=False)`) as a device kernel:
+// every sampled k-space location gets an i.i.d. 32-bit key from a counter-based hash of
+// (seed, step, problem, position); the `mb` smallest keys are the minibatch (uniform without replacement).
+// The threshold key is found by a 4-pass 8-bit radix select with an LDS histogram; equal keys at the
+// threshold (probability ~2^-32 per pair) are resolved by position, so a draw is deterministic.
+// The kernel also clears and fills the transposed selector, replacing memset + scatter.
+// NOT the NumPy legacy stream: reference-identical draws still come from the host (CSMRI.select_mb).
+__device__ __forceinline__ uint32_t mb_hash(uint64_t seed, uint32_t step, uint32_t prob, uint32_t j) {
+    uint64_t x = seed ^ ((uint64_t)step << 40) ^ ((uint64_t)prob << 20) ^ (uint64_t)j;
+    x += 0x9E3779B97F4A7C15ull;                                 // splitmix64 finaliser
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 32);
+}
+
+__global__ __launch_bounds__(1024) void k_draw_mb(const int32_t* __restrict__ mask_idx, int M0, int mb, uint64_t seed,
+                                                  uint32_t step, uint8_t* __restrict__ selT, int H, int W) {
+    __shared__ int hist[256];
+    __shared__ int s_bin, s_before, s_ntie;
+    __shared__ int tie[64];
+    const int prob = blockIdx.x, tid = threadIdx.x;
+    const int32_t* idx = mask_idx + (size_t)prob * M0;
+    uint8_t* out = selT + (size_t)prob * H * W;
+    for (int i = tid; i < H * W / 16; i += 1024) reinterpret_cast<uint4*>(out)[i] = make_uint4(0, 0, 0, 0);
+
+    uint32_t prefix = 0;
+    int k = mb;                                                  // rank (1-based) still to locate inside the prefix bucket
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int j = tid; j < M0; j += 1024) {
+            const uint32_t key = mb_hash(seed, step, prob, j);
+            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {                                          // one wave: 4 bins per lane, inclusive scan
+            const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const int tot = c0 + c1 + c2 + c3;
+            int incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += v;
+            }
+            const int excl = incl - tot;
+            if (excl < k && k <= incl) {                         // exactly one lane
+                int before = excl, bin = 4 * tid;
+                if (k > before + c0) { before += c0; ++bin;
+                    if (k > before + c1) { before += c1; ++bin;
+                        if (k > before + c2) { before += c2; ++bin; } } }
+                s_bin = bin;
+                s_before = before;
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (uint32_t)s_bin;
+        k -= s_before;
+        __syncthreads();
+    }
+    // prefix = the mb-th smallest key T; take every key < T and the k first (by position) keys == T
+    if (tid == 0) s_ntie = 0;
+    __syncthreads();
+    for (int j = tid; j < M0; j += 1024) {
+        const uint32_t key = mb_hash(seed, step, prob, j);
+        if (key < prefix) {
+            const int i = idx[j];
+            out[(size_t)(i % W) * H + i / W] = 1;
+        } else if (key == prefix) {
+            const int t = atomicAdd(&s_ntie, 1);
+            if (t < 64) tie[t] = j;
+        }
+    }
+    __syncthreads();
+    const int ntie = s_ntie < 64 ? s_ntie : 64;
+    if (tid < ntie) {
+        const int j = tie[tid];
+        int rank = 0;
+        for (int t = 0; t < ntie; ++t) rank += tie[t] < j ? 1 : 0;
+        if (rank < k) {
+            const int i = idx[j];
+            out[(size_t)(i % W) * H + i / W] = 1;
+        }
+    }
+}
+
 template <typename T> void fill_twiddles(std::vector<cx<T>>& tab, int N) {
     tab.resize(N);
     for (int j = 0; j < N; ++j) {
@@ -284,6 +372,15 @@ extern "C" int pnp_csmri_sel_from_indices(pnp_csmri_plan* p, const int32_t* idx,
         k_sel_scatter<<<dim3((n + 255) / 256, p->batch), 256, 0, s>>>(idx, n, selT, p->H, p->W);
         PNP_CHECK_LAUNCH();
     }
+    return PNP_OK;
+}
+
+extern "C" int pnp_csmri_draw_minibatch(pnp_csmri_plan* p, const int32_t* mask_idx, int M0, int mb, uint64_t seed,
+                                        uint32_t step, uint8_t* selT, void* stream) {
+    PNP_CHECK_ARG(p && mask_idx && selT, "null argument");
+    PNP_CHECK_ARG(M0 >= 1 && M0 <= p->H * p->W && mb >= 1 && mb <= M0, "need 1 <= mb <= M0 <= H*W");
+    k_draw_mb<<<p->batch, 1024, 0, (hipStream_t)stream>>>(mask_idx, M0, mb, seed, step, selT, p->H, p->W);
+    PNP_CHECK_LAUNCH();
     return PNP_OK;
 }
 

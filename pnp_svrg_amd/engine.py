@@ -6,9 +6,9 @@ w = z; inner: minibatch draw, SVRG direction, step, estimate_sigma, denoise, PSN
 sweep-style workloads of script_diff_*_set12.py, where many reconstructions are independent.
 Nothing is read back per iteration: squared errors (for PSNR) accumulate in a device log.
 
-Minibatches are *inputs*: index lists [n_steps][B][mb] resident in HBM (drawn beforehand, from
-the legacy `np.random` stream when reference-identical draws are wanted, or from a fast
-Generator for synthetic benchmarks).
+Minibatches: by default drawn on the device inside each step (`pnp_csmri_draw_minibatch`: hash keys +
+radix select, uniform without replacement); for reference-identical runs pass index lists drawn from
+the legacy `np.random` stream (`step(idx)`).
 """
 import numpy as np
 import torch
@@ -38,6 +38,8 @@ class CsmriBatch:
             raise ValueError('CsmriBatch needs the same number of sampled k-space points in every problem; '
                              'use synthetic(), which draws masks with a fixed count, or batch equal-M0 problems')
         self.mask_np = np.ascontiguousarray(mask, np.uint8)
+        # flatnonzero(mask) per problem (equal counts) for the device-side minibatch draw
+        self.mask_idx = torch.from_numpy(np.stack([np.flatnonzero(m) for m in self.mask_np.reshape(B, -1)]).astype(np.int32)).to(device)
 
     @classmethod
     def synthetic(cls, B, H=256, W=256, sample_prob=0.2, snr=20.0, seed=0, dtype=torch.float32):
@@ -119,7 +121,7 @@ class SvrgEngine:
     'reference' is what v1 executes (v = mu, :54).  `step(s)` = inner iteration s (the outer
     full-gradient refresh happens inside when s % T2 == 0, as in the reference's loop nest)."""
 
-    def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096):
+    def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096, seed=0):
         self.b, self.prox, self.eta, self.T2, self.mb, self.lr_decay, self.variant = batch, prox, eta, T2, mini_batch_size, lr_decay, variant
         dev = batch.xrec.device
         self.z = batch.xinit.clone()
@@ -128,6 +130,7 @@ class SvrgEngine:
         self.selT = torch.empty_like(batch.maskT)
         self.sse_log = torch.zeros((n_log, batch.B), dtype=torch.float64, device=dev)
         self.n_log = n_log
+        self.seed = seed
         prox.bind(batch)
         self.s = 0
 
@@ -137,15 +140,20 @@ class SvrgEngine:
         if hasattr(self.prox, 't'):
             self.prox.t = 0
 
-    def step(self, idx_s):
-        """One inner iteration for all B problems.  idx_s: int32 [B][mb] minibatch indices."""
+    def step(self, idx_s=None):
+        """One inner iteration for all B problems.  idx_s: int32 [B][mb] minibatch index lists (e.g. drawn
+        from NumPy's legacy stream for reference-identical runs); None = draw on the device (hash keys +
+        radix select, `pnp_csmri_draw_minibatch`), which keeps the draw inside the iteration like the reference."""
         b, s = self.b, self.s
         if s % self.T2 == 0:                                    # outer: mu = grad_full(z); w = z
             b.plan.grad(self.z, b.maskT, yh=b.yh_full, alpha=1.0 / float(b.M0[0]), out=self.mu)
             self.w.copy_(self.z)
         lr = self.eta * self.lr_decay ** (s // self.T2)
         if self.variant == 'svrg':
-            b.plan.sel_from_indices(idx_s, out=self.selT)
+            if idx_s is None:
+                b.plan.draw_minibatch(b.mask_idx, self.mb, self.seed, s, out=self.selT)
+            else:
+                b.plan.sel_from_indices(idx_s, out=self.selT)
             b.plan.grad(self.z, self.selT, b=self.w, alpha=-lr / self.mb, beta=1.0, c1=self.z, gamma=-lr, c2=self.mu, out=self.z)
         else:
             ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)

@@ -50,6 +50,15 @@ class CsmriPlan:
         N.call('pnp_csmri_sel_from_indices', self._h, _p(idx), idx.shape[1], _p(out), _stream())
         return out
 
+    def draw_minibatch(self, mask_idx, mb, seed, step, out=None):
+        """Device-side uniform draw of `mb` of each problem's sampled locations -> transposed selector.
+        mask_idx: int32 [B, M0] (flatnonzero(mask) per problem)."""
+        assert mask_idx.dtype == torch.int32 and mask_idx.shape[0] == self.B
+        out = out if out is not None else torch.empty((self.B, self.W, self.H), dtype=torch.uint8, device=mask_idx.device)
+        N.call('pnp_csmri_draw_minibatch', self._h, _p(mask_idx), mask_idx.shape[1], int(mb), int(seed) & (2 ** 64 - 1),
+               int(step) & 0xFFFFFFFF, _p(out), _stream())
+        return out
+
     def sel_from_dense(self, sel, out=None):
         assert sel.dtype == torch.uint8 and tuple(sel.shape) == (self.B, self.H, self.W)
         out = out if out is not None else torch.empty((self.B, self.W, self.H), dtype=torch.uint8, device=sel.device)

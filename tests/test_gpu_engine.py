@@ -66,3 +66,36 @@ def test_bench_line_smoke():
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in line
     assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1
+
+
+def test_device_minibatch_draw():
+    """pnp_csmri_draw_minibatch: exactly mb ones per problem, inside the mask, deterministic in (seed, step),
+    different across steps/problems, and uniform (every sampled location selected ~ mb/M0 of the time)."""
+    from pnp_svrg_amd.engine import CsmriBatch
+    B, n, mb = 4, 64, 100
+    batch = CsmriBatch.synthetic(B, n, n, 0.2, 20.0, seed=9)
+    M0 = int(batch.M0[0])
+    sel = batch.plan.draw_minibatch(batch.mask_idx, mb, seed=7, step=3)
+    s = sel.cpu().numpy()                                     # [B][W][H] transposed
+    assert s.dtype == np.uint8 and set(np.unique(s)) <= {0, 1}
+    assert (s.reshape(B, -1).sum(1) == mb).all()
+    maskT = batch.maskT.cpu().numpy()
+    assert (s <= maskT).all()
+    assert torch.equal(sel, batch.plan.draw_minibatch(batch.mask_idx, mb, seed=7, step=3))
+    assert not torch.equal(sel, batch.plan.draw_minibatch(batch.mask_idx, mb, seed=7, step=4))
+    assert not np.array_equal(s[0], s[1])
+    # uniformity: 400 draws, per-location frequency ~ Binomial(400, mb/M0)
+    cnt = np.zeros((B, n, n), np.int64)
+    T = 400
+    for t in range(T):
+        cnt += batch.plan.draw_minibatch(batch.mask_idx, mb, seed=11, step=t).cpu().numpy()
+    p = mb / M0
+    f = cnt[maskT == 1] / T
+    assert abs(f.mean() - p) < 1e-12 + 1e-9                   # exactly mb per draw
+    z = (f - p) / np.sqrt(p * (1 - p) / T)
+    assert np.abs(z).max() < 5.5 and abs(z.std() - 1.0) < 0.1
+    # edge: mb == M0 selects the whole mask; mb == 1 selects one location
+    full = batch.plan.draw_minibatch(batch.mask_idx, M0, seed=1, step=0)
+    assert torch.equal(full, batch.maskT)
+    one = batch.plan.draw_minibatch(batch.mask_idx, 1, seed=1, step=0)
+    assert (one.reshape(B, -1).sum(1) == 1).all()

@@ -163,6 +163,14 @@ def main():
                     'executed_tflops': round(ach * (2.0 / 3.0 if wino else 1.0), 2),
                     'executed_frac_of_mfma_peak': round(ach * (2.0 / 3.0 if wino else 1.0) / F32_MFMA_PEAK_TFLOPS, 4)}
 
+    if a.workload == 'tv':
+        # no single dominant kernel (rows_inv / prox / cols / rows_fwd ~ 20-27 % each): the whole step against HBM
+        alg = 2368 * 1024 * B                                    # 2 368 KiB per problem-iteration
+        ach = alg / (dt / a.steps) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': 'whole inner iteration (k_rows_fwd + k_cols + k_rows_inv + k_prox_tv + k_draw_mb)',
+                    'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                    'traffic': None, 'bytes_per_step': alg}
+
     # final gather of the results (the only collective on this path; outside the timed region)
     trace = eng.psnr_trace()
     psnr0 = float(np.mean(np.around(10 * np.log10(1.0 / ((batch.xinit - batch.xrec) ** 2).reshape(B, -1).mean(1).cpu().numpy()), 2)))

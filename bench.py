@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=16, help='independent reconstructions per GPU')
     ap.add_argument('--workload', default='dncnn', choices=['dncnn', 'tv'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo + PNP_BENCH_ONE_DEVICE=1 rehearses the N>1 path with all ranks on GPU 0')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
     return ap.parse_args()
 
@@ -91,8 +93,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.environ.get('PNP_BENCH_ONE_DEVICE') == '1':
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -133,8 +140,9 @@ def main():
         eng.step(idx[(a.warmup + s) % n_draw] if idx is not None else None)
     sync_all()
     dt = time.perf_counter() - t0
+    cdev = 'cuda' if (dist is None or a.backend == 'nccl') else 'cpu'      # where collective buffers live
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -174,7 +182,7 @@ def main():
     # final gather of the results (the only collective on this path; outside the timed region)
     trace = eng.psnr_trace()
     psnr0 = float(np.mean(np.around(10 * np.log10(1.0 / ((batch.xinit - batch.xrec) ** 2).reshape(B, -1).mean(1).cpu().numpy()), 2)))
-    final_psnr = torch.from_numpy(np.ascontiguousarray(trace[-1])).cuda()
+    final_psnr = torch.from_numpy(np.ascontiguousarray(trace[-1])).to(cdev)
     if dist is not None:
         gathered = [torch.empty_like(final_psnr) for _ in range(world)] if rank == 0 else None
         dist.gather(final_psnr, gathered, dst=0)

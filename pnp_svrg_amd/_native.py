@@ -39,6 +39,7 @@ SIGNATURES = {
     'pnp_minmax': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'pnp_dncnn_plan_create': (_i, [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'pnp_dncnn_plan_destroy': (_i, [_vp]),
+    'pnp_dncnn_set_winograd': (_i, [_vp, _i]),
     'pnp_dncnn_forward': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_dncnn_denoise': (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     'pnp_dncnn_profile_begin': (_i, [_vp, _i]),

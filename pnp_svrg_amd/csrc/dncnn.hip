@@ -683,6 +683,12 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
 }
 }  // namespace
 
+extern "C" int pnp_dncnn_set_winograd(pnp_dncnn_plan* p, int enable) {
+    PNP_CHECK_ARG(p != nullptr, "null plan");
+    p->use_wino = enable ? 1 : 0;
+    return PNP_OK;
+}
+
 extern "C" int pnp_dncnn_profile_begin(pnp_dncnn_plan* p, int max_calls) {
     PNP_CHECK_ARG(p && max_calls > 0, "bad argument");
     while (p->ev.size() < (size_t)2 * max_calls) {

@@ -93,10 +93,7 @@ class DncnnPlan:
         """winograd: True = F(2,3) conv kernel (default; fp32, 2/3 of the matrix-core work),
         False = direct implicit GEMM (bit-for-bit an fmaf chain), None = env PNP_DNCNN_WINOGRAD or True."""
         import numpy as np
-        import os
         require_gpu()
-        if winograd is not None:
-            os.environ['PNP_DNCNN_WINOGRAD'] = '1' if winograd else '0'
         n = int(weights['n_layers'])
         self.H, self.W, self.B, self.n_mid = H, W, batch, n - 2
         w_first = np.ascontiguousarray(weights['conv0.weight'], dtype=np.float32).reshape(64, 9)
@@ -115,6 +112,8 @@ class DncnnPlan:
                w_mid.ctypes.data_as(ctypes.c_void_p), b_mid.ctypes.data_as(ctypes.c_void_p),
                w_last.ctypes.data_as(ctypes.c_void_p), H, W, batch)
         self._h = h
+        if winograd is not None:
+            N.call('pnp_dncnn_set_winograd', self._h, 1 if winograd else 0)
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None

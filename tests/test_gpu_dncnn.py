@@ -77,17 +77,10 @@ def test_denoise_wrapper(W15, io, g_denoise, dtype):
 def test_winograd_vs_direct(W15, io):
     """The two conv kernels (Winograd F(2,3) default, direct fmaf-chain) agree to fp32 rounding, and both
     match the reference network."""
-    import os
     from pnp_svrg_amd import ops
     x = dev(io['net256_in'][None])
-    old = os.environ.get('PNP_DNCNN_WINOGRAD')
-    try:
-        rw = ops.DncnnPlan(W15, 256, 256, 1, winograd=True).forward(x).cpu().numpy()[0]
-        rd = ops.DncnnPlan(W15, 256, 256, 1, winograd=False).forward(x).cpu().numpy()[0]
-    finally:
-        if old is None:
-            os.environ.pop('PNP_DNCNN_WINOGRAD', None)
-        else:
-            os.environ['PNP_DNCNN_WINOGRAD'] = old
+    rw = ops.DncnnPlan(W15, 256, 256, 1, winograd=True).forward(x).cpu().numpy()[0]
+    rd = ops.DncnnPlan(W15, 256, 256, 1, winograd=False).forward(x).cpu().numpy()[0]
+    assert not np.array_equal(rw, rd)                          # really two different kernels
     assert np.abs(rw - rd).max() <= 1e-5
     assert np.abs(rw - io['net256_out']).max() <= 2e-5 and np.abs(rd - io['net256_out']).max() <= 2e-5

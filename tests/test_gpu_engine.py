@@ -122,3 +122,22 @@ def test_sweep_runner_single_process():
     assert res[0]['psnr_final'] > res[0]['psnr_init']          # 20 % sampling: the reconstruction helps
     # more samples -> better reconstruction of the same image
     assert res[2]['psnr_final'] > res[0]['psnr_final']
+
+
+def test_bench_two_ranks_rehearsal():
+    """The N > 1 path of bench.py (barrier, MAX over ranks, final gather) with 2 ranks sharing GPU 0 over gloo
+    (RCCL needs one GPU per rank; the driver runs the real N = 2/4/8 on a full node)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PNP_BENCH_ONE_DEVICE='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+                          '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2', '--backend', 'gloo',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['problems_total'] == 4 and line['scaling'] == 'weak'
+    assert line['value'] > 0 and line['cpu_baseline'] is None

@@ -84,3 +84,18 @@ def test_winograd_vs_direct(W15, io):
     assert not np.array_equal(rw, rd)                          # really two different kernels
     assert np.abs(rw - rd).max() <= 1e-5
     assert np.abs(rw - io['net256_out']).max() <= 2e-5 and np.abs(rd - io['net256_out']).max() <= 2e-5
+
+
+@pytest.mark.parametrize('name', ['SimpleCNN', 'RealSN_SimpleCNN'])
+def test_simplecnn_family(name):
+    """the 4-layer SimpleCNN / RealSN_SimpleCNN denoisers run through the same plan (n_mid = 2,
+    no BatchNorm).  Golden output = the reference's own class (incl. its spectral-norm eval hook for the RealSN
+    checkpoint) on its own weights."""
+    from pnp_svrg_amd import ops
+    g = golden('simplecnn_noise15.npz')
+    w = {'n_layers': np.int64(4)}
+    for i in range(4):
+        w[f'conv{i}.weight'] = g[f'{name}_conv{i}.weight']
+    for wino in (True, False):
+        r = ops.DncnnPlan(w, 64, 64, 1, winograd=wino).forward(dev(g['net64_in'][None])).cpu().numpy()[0]
+        assert np.abs(r - g[f'{name}_out']).max() <= 2e-5

@@ -35,7 +35,7 @@ const char* pnp_last_error(void);
  * computed with real FFTs on the Hermitian-symmetrised k-space residual.            */
 typedef struct pnp_csmri_plan pnp_csmri_plan;
 
-/* H == W in {64, 256}.  The plan owns a [batch][W/2][H] complex workspace + twiddles. */
+/* H == W in {64, 128, 256}.  The plan owns a [batch][W/2][H] complex workspace + twiddles. */
 int pnp_csmri_plan_create(pnp_csmri_plan** plan, int H, int W, int batch, int dtype);
 int pnp_csmri_plan_destroy(pnp_csmri_plan* plan);
 

@@ -22,39 +22,44 @@ namespace pnp {
 
 template <typename T> struct alignas(4 * sizeof(T)) vec4 { T a, b, c, d; };
 
-template <typename T, int NL> struct FftSmem {
-    static constexpr int N = NL * NL;
-    static constexpr int G = 256 / NL;                       // lane groups per 256-thread block
+// RA x LA = the register x lane split of one length-N transform (fft.h: fft_gen); RA == LA for N = 64, 256,
+// <8,16> for N = 128.  A lane group is LG = max(RA, LA) lanes.
+template <typename T, int RA, int LA> struct FftSmem {
+    static constexpr int N = RA * LA;
+    static constexpr int LG = RA > LA ? RA : LA;
+    static constexpr int G = 256 / LG;                       // lane groups per 256-thread block
     static constexpr int TILE = G * (N + 1);                 // [group][N+1] complex
-    static constexpr int SCR = G * NL * (NL + 1);            // [group][NL][NL+1] complex
+    static constexpr int SCR = G * LG * (LG + 1);            // [group][LG][LG+1] complex
     static constexpr int ELEMS = TILE > SCR ? TILE : SCR;
 };
 
 // ------------------------------------------------------------------------------- rows forward
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 __global__ __launch_bounds__(256) void k_rows_fwd(const T* __restrict__ a, const T* __restrict__ b,
                                                   cx<T>* __restrict__ S1T, const cx<T>* __restrict__ twtab, int H) {
-    using S = FftSmem<T, NL>;
-    constexpr int N = S::N, G = S::G;
+    using S = FftSmem<T, RA, LA>;
+    constexpr int N = S::N, G = S::G, LG = S::LG;
     __shared__ cx<T> smem[S::ELEMS];
-    const int t = threadIdx.x, g = t / NL, lane = t % NL;
+    const int t = threadIdx.x, g = t / LG, lane = t % LG;
     const int prob = blockIdx.y, h0 = blockIdx.x * 2 * G;
     const size_t img = (size_t)prob * H * N;
     const size_t ra = img + (size_t)(h0 + 2 * g) * N, rb = ra + N;
 
-    cx<T> v[NL], tw[NL];
-    load_twiddles<T, NL>(tw, twtab, lane);
+    cx<T> v[LG], tw[LG];
+    load_twiddles_gen<T, LG>(tw, twtab, lane, N);
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
-        const int w = lane + NL * r;
+    for (int r = 0; r < RA; ++r) {
+        const int w = (lane < LA ? lane : 0) + LA * r;
         T va = a[ra + w], vb = a[rb + w];
         if (b != nullptr) { va -= b[ra + w]; vb -= b[rb + w]; }
         v[r] = {va, vb};
     }
-    fft_group<T, NL, false>(v, tw, smem + g * NL * (NL + 1), lane);
+    fft_gen<T, RA, LA, false>(v, tw, smem + g * LG * (LG + 1), lane);
     __syncthreads();
+    if (lane < RA) {
 #pragma unroll
-    for (int r = 0; r < NL; ++r) smem[g * (N + 1) + lane + NL * r] = v[r];
+        for (int r = 0; r < LA; ++r) smem[g * (N + 1) + lane + RA * r] = v[r];
+    }
     __syncthreads();
 
     // split the two interleaved real transforms and store transposed
@@ -74,34 +79,38 @@ __global__ __launch_bounds__(256) void k_rows_fwd(const T* __restrict__ a, const
 }
 
 // ------------------------------------------------------------------------------- columns
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 __global__ __launch_bounds__(256) void k_cols(cx<T>* __restrict__ S1T, const uint8_t* __restrict__ selT,
                                               const cx<T>* __restrict__ yh, const cx<T>* __restrict__ twtab, int W) {
-    using S = FftSmem<T, NL>;
-    constexpr int N = S::N, G = S::G;                        // N = H
+    using S = FftSmem<T, RA, LA>;
+    constexpr int N = S::N, G = S::G, LG = S::LG;            // N = H
     __shared__ cx<T> smem[S::SCR];
-    const int t = threadIdx.x, g = t / NL, lane = t % NL;
+    const int t = threadIdx.x, g = t / LG, lane = t % LG;
     const int prob = blockIdx.y, c = blockIdx.x * G + g;
     cx<T>* col = S1T + ((size_t)prob * (W / 2) + c) * N;
-    cx<T>* scr = smem + g * NL * (NL + 1);
+    cx<T>* scr = smem + g * LG * (LG + 1);
+    const bool act = lane < RA;                              // lanes that hold spectrum values after the forward pass
+    const int ln = act ? lane : 0;
 
-    cx<T> v[NL], tw[NL];
-    load_twiddles<T, NL>(tw, twtab, lane);
+    cx<T> v[LG], tw[LG];
+    load_twiddles_gen<T, LG>(tw, twtab, lane, N);
 #pragma unroll
-    for (int r = 0; r < NL; ++r) v[r] = col[lane + NL * r];
-    fft_group<T, NL, false>(v, tw, scr, lane);
+    for (int r = 0; r < RA; ++r) v[r] = col[(lane < LA ? lane : 0) + LA * r];
+    fft_gen<T, RA, LA, false>(v, tw, scr, lane);
 
     const uint8_t* sp = selT + (size_t)prob * W * N;
     if (blockIdx.x == 0) {
         // the packed column c == 0 holds two real-input transforms: separate, weight, re-pack
         __syncthreads();
+        if (act) {
 #pragma unroll
-        for (int r = 0; r < NL; ++r) scr[lane + NL * r] = v[r];
+            for (int r = 0; r < LA; ++r) scr[lane + RA * r] = v[r];
+        }
         __syncthreads();
         if (g == 0) {
 #pragma unroll
-            for (int r = 0; r < NL; ++r) {
-                const int ky = lane + NL * r, km = (N - ky) & (N - 1);
+            for (int r = 0; r < LA; ++r) {
+                const int ky = ln + RA * r, km = (N - ky) & (N - 1);
                 const cx<T> pk = v[r], pm = scr[km];
                 const cx<T> A = {(T)0.5 * (pk.x + pm.x), (T)0.5 * (pk.y - pm.y)};
                 const cx<T> B = {(T)0.5 * (pk.y + pm.y), (T)-0.5 * (pk.x - pm.x)};
@@ -115,8 +124,8 @@ __global__ __launch_bounds__(256) void k_cols(cx<T>* __restrict__ S1T, const uin
         const uint8_t* s1 = sp + (size_t)c * N;
         const uint8_t* s2 = sp + (size_t)(W - c) * N;
 #pragma unroll
-        for (int r = 0; r < NL; ++r) {
-            const int ky = lane + NL * r, km = (N - ky) & (N - 1);
+        for (int r = 0; r < LA; ++r) {
+            const int ky = ln + RA * r, km = (N - ky) & (N - 1);
             const T wgt = (T)0.5 * (T)(s1[ky] + s2[km]);
             v[r] = {wgt * v[r].x, wgt * v[r].y};
         }
@@ -124,21 +133,23 @@ __global__ __launch_bounds__(256) void k_cols(cx<T>* __restrict__ S1T, const uin
     if (yh != nullptr) {
         const cx<T>* yc = yh + ((size_t)prob * (W / 2) + c) * N;
 #pragma unroll
-        for (int r = 0; r < NL; ++r) v[r] = csub(v[r], yc[lane + NL * r]);
+        for (int r = 0; r < LA; ++r) v[r] = csub(v[r], yc[ln + RA * r]);
     }
-    fft_group<T, NL, true>(v, tw, scr, lane);
+    fft_gen<T, LA, RA, true>(v, tw, scr, lane);
+    if (lane < LA) {
 #pragma unroll
-    for (int r = 0; r < NL; ++r) col[lane + NL * r] = v[r];
+        for (int r = 0; r < RA; ++r) col[lane + LA * r] = v[r];
+    }
 }
 
 // ------------------------------------------------------------------------------- rows inverse + epilogue
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 __global__ __launch_bounds__(256) void k_rows_inv(const cx<T>* __restrict__ S1T, const cx<T>* __restrict__ twtab, int H,
                                                   T alpha, T beta, const T* c1, T gamma, const T* c2, T* out) {
-    using S = FftSmem<T, NL>;
-    constexpr int N = S::N, G = S::G;
+    using S = FftSmem<T, RA, LA>;
+    constexpr int N = S::N, G = S::G, LG = S::LG;
     __shared__ cx<T> smem[S::ELEMS];
-    const int t = threadIdx.x, g = t / NL, lane = t % NL;
+    const int t = threadIdx.x, g = t / LG, lane = t % LG;
     const int prob = blockIdx.y, h0 = blockIdx.x * 2 * G;
 
     const int p = t % G;
@@ -154,21 +165,23 @@ __global__ __launch_bounds__(256) void k_rows_inv(const cx<T>* __restrict__ S1T,
         }
     }
     __syncthreads();
-    cx<T> v[NL], tw[NL];
-    load_twiddles<T, NL>(tw, twtab, lane);
+    cx<T> v[LG], tw[LG];
+    load_twiddles_gen<T, LG>(tw, twtab, lane, N);
 #pragma unroll
-    for (int r = 0; r < NL; ++r) v[r] = smem[g * (N + 1) + lane + NL * r];
-    fft_group<T, NL, true>(v, tw, smem + g * NL * (NL + 1), lane);
+    for (int r = 0; r < LA; ++r) v[r] = smem[g * (N + 1) + (lane < RA ? lane : 0) + RA * r];
+    fft_gen<T, LA, RA, true>(v, tw, smem + g * LG * (LG + 1), lane);
 
     const size_t ra = (size_t)prob * H * N + (size_t)(h0 + 2 * g) * N, rb = ra + N;
+    if (lane < LA) {
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
-        const int w = lane + NL * r;
-        T oa = alpha * v[r].x, ob = alpha * v[r].y;
-        if (c1 != nullptr) { oa += beta * c1[ra + w]; ob += beta * c1[rb + w]; }
-        if (c2 != nullptr) { oa += gamma * c2[ra + w]; ob += gamma * c2[rb + w]; }
-        out[ra + w] = oa;
-        out[rb + w] = ob;
+        for (int r = 0; r < RA; ++r) {
+            const int w = lane + LA * r;
+            T oa = alpha * v[r].x, ob = alpha * v[r].y;
+            if (c1 != nullptr) { oa += beta * c1[ra + w]; ob += beta * c1[rb + w]; }
+            if (c2 != nullptr) { oa += gamma * c2[ra + w]; ob += gamma * c2[rb + w]; }
+            out[ra + w] = oa;
+            out[rb + w] = ob;
+        }
     }
 }
 
@@ -322,17 +335,17 @@ template <typename T> void fill_twiddles(std::vector<cx<T>>& tab, int N) {
 using namespace pnp;
 
 struct pnp_csmri_plan {
-    int H, W, batch, dtype, NL;
+    int H, W, batch, dtype, NL;              // NL: 16 -> N = 256, 8 -> N = 64, 12 -> N = 128 (8 x 16 split)
     void* work;     // [batch][W/2][H] complex
     void* twtab;    // [N] complex
 };
 
 extern "C" int pnp_csmri_plan_create(pnp_csmri_plan** out, int H, int W, int batch, int dtype) {
     PNP_CHECK_ARG(out != nullptr, "null plan pointer");
-    PNP_CHECK_ARG(H == W && (H == 64 || H == 256), "supported sizes: H == W in {64, 256}");
+    PNP_CHECK_ARG(H == W && (H == 64 || H == 128 || H == 256), "supported sizes: H == W in {64, 128, 256}");
     PNP_CHECK_ARG(batch >= 1, "batch must be >= 1");
     PNP_CHECK_ARG(dtype == PNP_F32 || dtype == PNP_F64, "dtype must be PNP_F32 or PNP_F64");
-    auto* p = new pnp_csmri_plan{H, W, batch, dtype, H == 256 ? 16 : 8, nullptr, nullptr};
+    auto* p = new pnp_csmri_plan{H, W, batch, dtype, H == 256 ? 16 : H == 128 ? 12 : 8, nullptr, nullptr};
     const size_t esz = dtype == PNP_F32 ? 8 : 16;
     hipError_t e = hipMalloc(&p->work, (size_t)batch * (W / 2) * H * esz);
     if (e == hipSuccess) e = hipMalloc(&p->twtab, (size_t)H * esz);
@@ -405,19 +418,19 @@ extern "C" int pnp_csmri_pack_y(pnp_csmri_plan* p, const void* YT, const uint8_t
 }
 
 namespace {
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 int run_grad(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const void* yh, double alpha,
              double beta, const void* c1, double gamma, const void* c2, void* out, hipStream_t s) {
-    constexpr int G = 256 / NL;
+    constexpr int G = FftSmem<T, RA, LA>::G;
     const int H = p->H, W = p->W;
     cx<T>* work = (cx<T>*)p->work;
     const cx<T>* tw = (const cx<T>*)p->twtab;
     const T scale = (T)(alpha / ((double)H * (double)W));
-    k_rows_fwd<T, NL><<<dim3(H / (2 * G), p->batch), 256, 0, s>>>((const T*)a, (const T*)b, work, tw, H);
+    k_rows_fwd<T, RA, LA><<<dim3(H / (2 * G), p->batch), 256, 0, s>>>((const T*)a, (const T*)b, work, tw, H);
     PNP_CHECK_LAUNCH();
-    k_cols<T, NL><<<dim3((W / 2) / G, p->batch), 256, 0, s>>>(work, selT, (const cx<T>*)yh, tw, W);
+    k_cols<T, RA, LA><<<dim3((W / 2) / G, p->batch), 256, 0, s>>>(work, selT, (const cx<T>*)yh, tw, W);
     PNP_CHECK_LAUNCH();
-    k_rows_inv<T, NL><<<dim3(H / (2 * G), p->batch), 256, 0, s>>>(work, tw, H, scale, (T)beta, (const T*)c1, (T)gamma,
+    k_rows_inv<T, RA, LA><<<dim3(H / (2 * G), p->batch), 256, 0, s>>>(work, tw, H, scale, (T)beta, (const T*)c1, (T)gamma,
                                                                  (const T*)c2, (T*)out);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
@@ -430,9 +443,11 @@ extern "C" int pnp_csmri_grad(pnp_csmri_plan* p, const void* a, const void* b, c
     PNP_CHECK_ARG(p && a && selT && out, "null argument");
     hipStream_t s = (hipStream_t)stream;
     if (p->dtype == PNP_F32) {
-        if (p->NL == 16) return run_grad<float, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
-        return run_grad<float, 8>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+        if (p->NL == 16) return run_grad<float, 16, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+        if (p->NL == 12) return run_grad<float, 8, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+        return run_grad<float, 8, 8>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
     }
-    if (p->NL == 16) return run_grad<double, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
-    return run_grad<double, 8>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+    if (p->NL == 16) return run_grad<double, 16, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+    if (p->NL == 12) return run_grad<double, 8, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+    return run_grad<double, 8, 8>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
 }

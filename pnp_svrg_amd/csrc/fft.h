@@ -73,4 +73,44 @@ __device__ __forceinline__ void fft_group(cx<T> (&v)[NL], const cx<T> (&tw)[NL],
     dft_reg<T, NL, INV>(v);
 }
 
+// General (rectangular) form: N = RA * LA points; input spread over LA lanes x RA registers (element
+// lane + LA*r), output over RA lanes x LA registers (element lane + RA*r), both natural order.  The lane
+// group is max(RA, LA) wide; after the call only lanes < RA hold results.  A forward <RA, LA> followed by an
+// inverse <LA, RA> returns to the input layout, so FFT -> pointwise -> inverse FFT still chains in registers.
+// RA == LA is the square case above (N = 64, 256); <8,16>/<16,8> give N = 128.
+// Whole-block collective (contains __syncthreads).  scr: group-private LDS, MX*(MX+1) complex, MX = max(RA, LA).
+// tw[r] = W_N^(lane*r) for r < MX (load_twiddles_gen).
+template <typename T, int RA, int LA, bool INV>
+__device__ __forceinline__ void fft_gen(cx<T> (&v)[(RA > LA ? RA : LA)], const cx<T> (&tw)[(RA > LA ? RA : LA)], cx<T>* scr, int lane) {
+    {
+        cx<T> a[RA];
+#pragma unroll
+        for (int r = 0; r < RA; ++r) a[r] = v[r];
+        dft_reg<T, RA, INV>(a);
+#pragma unroll
+        for (int r = 0; r < RA; ++r) v[r] = cmul(a[r], INV ? cconj(tw[r]) : tw[r]);
+    }
+    __syncthreads();
+    if (lane < LA) {
+#pragma unroll
+        for (int r = 0; r < RA; ++r) scr[r * (LA + 1) + lane] = v[r];
+    }
+    __syncthreads();
+    {
+        cx<T> b[LA];
+        const int ln = lane < RA ? lane : 0;                 // idle lanes read a valid slot (results unused)
+#pragma unroll
+        for (int r = 0; r < LA; ++r) b[r] = scr[ln * (LA + 1) + r];
+        dft_reg<T, LA, INV>(b);
+#pragma unroll
+        for (int r = 0; r < LA; ++r) v[r] = b[r];
+    }
+}
+
+template <typename T, int MX>
+__device__ __forceinline__ void load_twiddles_gen(cx<T> (&tw)[MX], const cx<T>* __restrict__ table, int lane, int N) {
+#pragma unroll
+    for (int r = 0; r < MX; ++r) tw[r] = table[(lane * r) & (N - 1)];
+}
+
 }  // namespace pnp

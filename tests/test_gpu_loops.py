@@ -205,3 +205,37 @@ def test_dncnn_denoiser_surface(api, g_denoise):
     np.testing.assert_allclose(out, io['den64_s15'], rtol=0, atol=3e-5)
     with pytest.raises(FileNotFoundError):                            # CWD-relative checkpoint path, as the reference
         D.RealSN_DnCNNDenoiser('RealSN_DnCNN', 5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_csmri_128(api, dtype):
+    """128 x 128 (the size the reference's CSMRI/PR notebooks use): rectangular 8 x 16 FFT split.  No golden
+    file at this size -> gradients and a short SVRG run against the (golden-pinned) oracle on the same seeds."""
+    from oracle import denoise as od, problems as op
+    A, P, D = api
+    np.random.seed(0)
+    p = P.CSMRI(IMG256, H=128, W=128, sample_prob=0.5, snr=10., dtype=dtype)       # PIL resizes 256 -> 128
+    np.random.seed(0)
+    po = op.CSMRI(IMG256, H=128, W=128, sample_prob=0.5, snr=10.)
+    assert np.array_equal(p.mask, po.mask) and p.M0 == po.M0
+    np.random.seed(7)
+    mb = p.select_mb(500)
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    gf, gfo = p.grad_full(po.Xinit), po.grad_full(po.Xinit)
+    assert np.abs(gf - gfo).max() <= tol * np.abs(gfo).max() * 10
+    gs, gso = p.grad_stoch(po.Xinit, mb), po.grad_stoch(po.Xinit, mb)
+    assert np.abs(gs - gso).max() <= tol * np.abs(gso).max() * 10
+    for variant in ('reference', 'svrg'):
+        np.random.seed(1)
+        r = A.pnp_svrg(p, D.TVDenoiser(), 0.1, 2 + 2 * (3 + 5 * 4), 4, 500, verbose=False, converge_check=False,
+                       clock=ol.CountingClock(), variant=variant)
+        np.random.seed(1)
+        ro = ol.pnp_svrg(po, od.TVDenoiser(), 0.1, 2 + 2 * (3 + 5 * 4), 4, 500, converge_check=False,
+                         clock=ol.CountingClock(), variant=variant)
+        ps, pso = np.array(r['psnr_per_iter']), np.array(ro['psnr_per_iter'])
+        assert len(ps) == len(pso)
+        if dtype == torch.float64:
+            assert list(ps) == list(pso)
+            np.testing.assert_allclose(r['z'], ro['z'], rtol=0, atol=1e-9)
+        else:
+            assert np.abs(ps - pso).max() <= 0.01 + 1e-9

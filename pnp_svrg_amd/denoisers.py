@@ -197,3 +197,17 @@ class NLMDenoiser(Denoise):
         if isinstance(noisy, torch.Tensor):
             return out.reshape(noisy.shape)
         return out.reshape(H, W).double().cpu().numpy()
+
+
+class MMODenoiser(Denoise):
+    """reference denoisers/MMODenoise.py:105-128.  Its checkpoints are whole pickled modules (loadable only
+    with weights_only=False, i.e. arbitrary code execution) and it is not on any BASELINE config: out of scope
+    (SURVEY section 2, 8f n3).  The class exists so that `from denoisers.MMODenoise import MMODenoiser`
+    (reference pnp_csmri.py:7) keeps importing."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self._args = (args, kwargs)
+
+    def denoise(self, noisy, sigma_est=0):
+        raise NotImplementedError('MMODenoiser is not part of the MI355X hot path (pickled-module checkpoints)')

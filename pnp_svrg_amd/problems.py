@@ -107,8 +107,34 @@ class Problem():
         # the reference divides the NORM (not its square) by the linear SNR; kept as is
         return np.sqrt(np.linalg.norm(self.Y0.ravel()) / 10 ** (self.snr / 10) / self.H / self.W)
 
-    def display(self, *args, **kwargs):
-        raise NotImplementedError('plotting is out of scope of the MI355X hot path (SURVEY section 2)')
+    def display(self, color_map='gray', show_measurements=False, save_results=False, save_dir='figures/', show_figs=False):
+        """reference problems/problem.py:64-108 (host-side matplotlib convenience, not on the hot path): shows /
+        saves the original image, the initialisation and optionally the measurements, and -- what callers such
+        as Utilities.display_results rely on -- sets `color_map` and `prob_dir`."""
+        self.color_map = color_map
+        import matplotlib.pyplot as plt
+        base = None
+        if save_results:
+            from datetime import datetime
+            import os
+            base = save_dir + self.pname + '/' + datetime.now().strftime('%y-%m-%d-%H-%M') + "/"
+            self.prob_dir = base
+            os.makedirs(base, exist_ok=True)
+        panels = [('Original Image', self.Xrec, 'original.eps'),
+                  ('Initialization', self.Xinit.reshape(self.H, self.W), 'initialization.eps')]
+        if show_measurements:
+            panels.append(('Measurements', np.real(self.Y).reshape(self.lrH, self.lrW), 'measurements.eps'))
+        for title, img, fname in panels:
+            fig = plt.figure(figsize=(6, 6))
+            plt.imshow(img, cmap=color_map, vmin=0, vmax=1)
+            plt.title(title)
+            plt.xticks([])
+            plt.yticks([])
+            if save_results:
+                fig.savefig(base + fname, transparent=True, bbox_inches='tight', pad_inches=0)
+            if show_figs:
+                plt.show()
+            plt.close(fig)
 
     def select_mb(self, size):
         if size > self.M:

@@ -171,3 +171,14 @@ def test_sweep_csv(tmp_path):
     sweep.write_csv(str(p), res, denoiser='DnCNN')
     rows = p.read_text().strip().splitlines()
     assert rows[0] == 'Problem,Denoiser,Algorithm,Alpha,SNR,Loss,PARAMETERS' and len(rows) == 3
+
+
+def test_reference_driver_imports():
+    """The import block of reference pnp_csmri.py:6-9 works against the drop-in packages."""
+    ns = {}
+    exec("from denoisers import *\nfrom denoisers.MMODenoise import MMODenoiser\nfrom problems import *\nfrom algorithms import *", ns)
+    for n in ('CSMRI', 'Deblur', 'PhaseRetrieval', 'BM3DDenoiser', 'NLMDenoiser', 'TVDenoiser', 'RealSN_DnCNNDenoiser',
+              'MMODenoiser', 'pnp_gd', 'pnp_sgd', 'pnp_svrg', 'pnp_saga', 'pnp_sarah'):
+        assert n in ns, n
+    # constructing the classic denoisers needs no GPU (pnp_csmri.py:18-20 does it at import time)
+    ns['BM3DDenoiser'](); ns['NLMDenoiser'](); ns['TVDenoiser']()

@@ -239,3 +239,12 @@ def test_csmri_128(api, dtype):
             np.testing.assert_allclose(r['z'], ro['z'], rtol=0, atol=1e-9)
         else:
             assert np.abs(ps - pso).max() <= 0.01 + 1e-9
+
+
+def test_problem_display_sets_attrs(api, tmp_path):
+    """problems/problem.py:64-108: callers (Utilities.display_results) read color_map / prob_dir afterwards."""
+    A, P, D = api
+    p = _csmri(P, IMG64, 64, torch.float32)
+    p.display(color_map='gray', show_measurements=True, save_results=True, save_dir=str(tmp_path) + '/')
+    assert p.color_map == 'gray' and p.prob_dir.startswith(str(tmp_path)) and os.path.isdir(p.prob_dir)
+    assert sorted(os.listdir(p.prob_dir)) == ['initialization.eps', 'measurements.eps', 'original.eps']

@@ -248,3 +248,31 @@ def test_problem_display_sets_attrs(api, tmp_path):
     p.display(color_map='gray', show_measurements=True, save_results=True, save_dir=str(tmp_path) + '/')
     assert p.color_map == 'gray' and p.prob_dir.startswith(str(tmp_path)) and os.path.isdir(p.prob_dir)
     assert sorted(os.listdir(p.prob_dir)) == ['initialization.eps', 'measurements.eps', 'original.eps']
+
+
+def test_config3_full_size_vs_oracle(api, g_csmri):
+    """BASELINE config 3 at full size: 256 x 256 CSMRI (20 % mask) on the photograph fixture, DnCNN prox with the
+    reference's sigma=15 weights, pnp_svrg (both directions), f32 device path with the default (Winograd) conv
+    kernel: every logged PSNR within +-0.01 dB of the oracle loop (torch-CPU fp32 net) on identical seeds."""
+    from conftest import golden
+    from oracle import denoise as od, problems as op
+    A, P, D = api
+    wts = dict(golden('dncnn_noise15.npz'))
+    img = g_csmri['r256_img']
+    for variant in ('reference', 'svrg'):
+        np.random.seed(0)
+        p = P.CSMRI(None, H=256, W=256, sample_prob=0.2, snr=20., img=img, dtype=torch.float32)
+        assert np.array_equal(p.mask, g_csmri['r256_mask'])
+        np.random.seed(1)
+        r = A.pnp_svrg(p, D.RealSN_DnCNNDenoiser('DnCNN', 15, weights=wts), 2e3, 2 + 2 * (3 + 5 * 5), 5, 1000,
+                       verbose=False, converge_check=False, clock=ol.CountingClock(), variant=variant)
+        np.random.seed(0)
+        po = op.CSMRI(None, H=256, W=256, sample_prob=0.2, snr=20., img=img)
+        np.random.seed(1)
+        ro = ol.pnp_svrg(po, od.DnCNNDenoiser(wts, 15), 2e3, 2 + 2 * (3 + 5 * 5), 5, 1000, converge_check=False,
+                         clock=ol.CountingClock(), variant=variant)
+        ps, pso = np.array(r['psnr_per_iter']), np.array(ro['psnr_per_iter'])
+        assert len(ps) == len(pso) == 13
+        assert np.abs(ps - pso).max() <= 0.01 + 1e-9, (ps, pso)
+        assert ps[-1] > ps[0] + 1.0                              # and it actually reconstructs
+        assert np.abs(r['z'] - ro['z']).max() < 5e-4

@@ -54,7 +54,9 @@ def cpu_baseline(workload, weights, budget_s=12.0):
     """The oracle (oracle/: NumPy + torch-CPU restatement of the reference path) on the host cores:
     the same inner iteration, one problem at a time, for ~budget_s seconds."""
     from oracle import problems as op, denoise as od
-    threads = torch.get_num_threads()
+    # a one-GPU box gets a 16-CPU share: more threads than that only oversubscribe the cgroup
+    threads = min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(threads)
     np.random.seed(0)
     rng = np.random.default_rng(0)
     x = rng.random((H, W))

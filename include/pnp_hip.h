@@ -69,7 +69,7 @@ int pnp_csmri_grad(pnp_csmri_plan* plan, const void* a, const void* b, const uin
 /* ------------------------------------------------------------------ Deblur / super-resolution
  * Replaces problems/DeblurSR.py:119-147: 1-D circular blur of the raveled image via a length-H*W FFT
  * (spectrum of the kernel computed once at plan creation), optional 4-tap bilinear down-sampler
- * (pylops Bilinear semantics; its adjoint as a deterministic CSR gather).  H*W in {4096, 65536}.
+ * (pylops Bilinear semantics; its adjoint as a deterministic CSR gather).  H*W in {64^2, 128^2, 256^2}.
  * Plan-creation arrays are HOST pointers: Bk [H*W] blur kernel (DeblurSR.py:93, already / N, `dtype`);
  * for scale_percent == 100 pass M = H*W and NULL operators; else g_idx/g_w [M][4] (forward taps) and
  * a_rowptr [H*W+1], a_col/a_val [nnz] (CSR of the adjoint).                                       */

@@ -22,11 +22,14 @@
 
 namespace pnp {
 
-template <typename T, int NL> struct LineSmem {
-    static constexpr int N = NL * NL;
-    static constexpr int G = 256 / NL;
+// RA x LA = register x lane split of one length-n line transform (fft.h: fft_gen): <8,8> n = 64, <8,16> n = 128,
+// <16,16> n = 256.
+template <typename T, int RA, int LA> struct LineSmem {
+    static constexpr int N = RA * LA;
+    static constexpr int LG = RA > LA ? RA : LA;
+    static constexpr int G = 256 / LG;
     static constexpr int TILE = G * (N + 1);
-    static constexpr int SCR = G * NL * (NL + 1);
+    static constexpr int SCR = G * LG * (LG + 1);
     static constexpr int ELEMS = TILE > SCR ? TILE : SCR;
 };
 
@@ -35,14 +38,14 @@ template <typename T, int NL> struct LineSmem {
 //   IN_REAL : input real T [n][n]           else complex
 //   TWIDDLE : multiply output k1 of column b by W_N^(+-b*k1)
 //   OUT_REAL: out real = sel ? alpha*Re(v) + beta*c : 0      else complex
-template <typename T, int NL, bool INV, bool IN_REAL, bool TWIDDLE, bool OUT_REAL>
+template <typename T, int RA, int LA, bool INV, bool IN_REAL, bool TWIDDLE, bool OUT_REAL>
 __global__ __launch_bounds__(256) void k_colpass(const void* __restrict__ in_, void* __restrict__ out_,
                                                  const cx<T>* __restrict__ tw_line, const cx<T>* __restrict__ tw_big,
                                                  T alpha, T beta, const T* __restrict__ c, const uint8_t* __restrict__ sel) {
-    using S = LineSmem<T, NL>;
-    constexpr int N = S::N, G = S::G;
+    using S = LineSmem<T, RA, LA>;
+    constexpr int N = S::N, G = S::G, LG = S::LG;
     __shared__ cx<T> smem[S::ELEMS];
-    const int t = threadIdx.x, g = t / NL, lane = t % NL;
+    const int t = threadIdx.x, g = t / LG, lane = t % LG;
     const int prob = blockIdx.y, b0 = blockIdx.x * G;
     const size_t base = (size_t)prob * N * N;
     const int p = t % G;
@@ -54,22 +57,24 @@ __global__ __launch_bounds__(256) void k_colpass(const void* __restrict__ in_, v
         smem[p * (N + 1) + a] = val;
     }
     __syncthreads();
-    cx<T> v[NL], tw[NL];
-    load_twiddles<T, NL>(tw, tw_line, lane);
+    cx<T> v[LG], tw[LG];
+    load_twiddles_gen<T, LG>(tw, tw_line, lane, N);
 #pragma unroll
-    for (int r = 0; r < NL; ++r) v[r] = smem[g * (N + 1) + lane + NL * r];
-    fft_group<T, NL, INV>(v, tw, smem + g * NL * (NL + 1), lane);
+    for (int r = 0; r < RA; ++r) v[r] = smem[g * (N + 1) + (lane < LA ? lane : 0) + LA * r];
+    fft_gen<T, RA, LA, INV>(v, tw, smem + g * LG * (LG + 1), lane);
     __syncthreads();
+    if (lane < RA) {
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
-        const int k1 = lane + NL * r;
-        cx<T> o = v[r];
-        if (TWIDDLE) {
-            cx<T> w = tw_big[(size_t)(b0 + g) * k1];
-            if (INV) w = cconj(w);
-            o = cmul(o, w);
+        for (int r = 0; r < LA; ++r) {
+            const int k1 = lane + RA * r;
+            cx<T> o = v[r];
+            if (TWIDDLE) {
+                cx<T> w = tw_big[(size_t)(b0 + g) * k1];
+                if (INV) w = cconj(w);
+                o = cmul(o, w);
+            }
+            smem[g * (N + 1) + k1] = o;
         }
-        smem[g * (N + 1) + k1] = o;
     }
     __syncthreads();
     for (int k1 = t / G; k1 < N; k1 += 256 / G) {
@@ -88,35 +93,42 @@ __global__ __launch_bounds__(256) void k_colpass(const void* __restrict__ in_, v
 
 // Contiguous lines (one per k1): forward DFT -> [x mul or conj(mul)] -> (SPECTRUM_ONLY: store) else
 // inverse DFT -> x conj(W_N^(k1*m2)) -> store.  In place allowed.
-template <typename T, int NL, bool CONJ, bool SPECTRUM_ONLY>
+template <typename T, int RA, int LA, bool CONJ, bool SPECTRUM_ONLY>
 __global__ __launch_bounds__(256) void k_rowpass(const cx<T>* in, cx<T>* out, const cx<T>* __restrict__ tw_line,
                                                  const cx<T>* __restrict__ tw_big, const cx<T>* __restrict__ mul) {
-    using S = LineSmem<T, NL>;
-    constexpr int N = S::N, G = S::G;
+    using S = LineSmem<T, RA, LA>;
+    constexpr int N = S::N, G = S::G, LG = S::LG;
     __shared__ cx<T> smem[S::SCR];
-    const int t = threadIdx.x, g = t / NL, lane = t % NL;
+    const int t = threadIdx.x, g = t / LG, lane = t % LG;
     const int prob = blockIdx.y, k1 = blockIdx.x * G + g;
     const size_t base = (size_t)prob * N * N + (size_t)k1 * N;
-    cx<T> v[NL], tw[NL];
-    load_twiddles<T, NL>(tw, tw_line, lane);
+    cx<T> v[LG], tw[LG];
+    load_twiddles_gen<T, LG>(tw, tw_line, lane, N);
 #pragma unroll
-    for (int r = 0; r < NL; ++r) v[r] = in[base + lane + NL * r];
-    fft_group<T, NL, false>(v, tw, smem + g * NL * (NL + 1), lane);
+    for (int r = 0; r < RA; ++r) v[r] = in[base + (lane < LA ? lane : 0) + LA * r];
+    fft_gen<T, RA, LA, false>(v, tw, smem + g * LG * (LG + 1), lane);     // -> lanes < RA, element lane + RA*r
+    const int ln = lane < RA ? lane : 0;
     if (mul != nullptr) {
 #pragma unroll
-        for (int r = 0; r < NL; ++r) {
-            cx<T> m = mul[(size_t)k1 * N + lane + NL * r];
+        for (int r = 0; r < LA; ++r) {
+            cx<T> m = mul[(size_t)k1 * N + ln + RA * r];
             if (CONJ) m = cconj(m);
             v[r] = cmul(v[r], m);
         }
     }
-    if (!SPECTRUM_ONLY) {
-        fft_group<T, NL, true>(v, tw, smem + g * NL * (NL + 1), lane);
+    if (SPECTRUM_ONLY) {
+        if (lane < RA) {
 #pragma unroll
-        for (int r = 0; r < NL; ++r) v[r] = cmul(v[r], cconj(tw_big[(size_t)k1 * (lane + NL * r)]));
+            for (int r = 0; r < LA; ++r) out[base + lane + RA * r] = v[r];
+        }
+    } else {
+        fft_gen<T, LA, RA, true>(v, tw, smem + g * LG * (LG + 1), lane);   // -> lanes < LA, element lane + LA*r
+        if (lane < LA) {
+#pragma unroll
+            for (int r = 0; r < RA; ++r)
+                out[base + lane + LA * r] = cmul(v[r], cconj(tw_big[(size_t)k1 * (lane + LA * r)]));
+        }
     }
-#pragma unroll
-    for (int r = 0; r < NL; ++r) out[base + lane + NL * r] = v[r];
 }
 
 // 4-tap sparse operator (pylops Bilinear forward / its CSR adjoint): out[m] = sum_t w[m][t] * x[idx[m][t]]
@@ -163,48 +175,48 @@ struct pnp_deblur_plan {
 
 namespace {
 // real [batch][N] -> Y[k1][b] (complex, work buffer w0)
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 int col_fwd(pnp_deblur_plan* p, const T* x, int batch, hipStream_t s) {
-    constexpr int G = 256 / NL;
-    k_colpass<T, NL, false, true, true, false><<<dim3(p->n / G, batch), 256, 0, s>>>(
+    constexpr int G = LineSmem<T, RA, LA>::G;
+    k_colpass<T, RA, LA, false, true, true, false><<<dim3(p->n / G, batch), 256, 0, s>>>(
         x, p->w0, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big, (T)0, (T)0, nullptr, nullptr);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }
 
 // one blur: out = sel ? alpha * (x (*) kernel) * sqrt(N)-normalised + beta*c : 0
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 int blur(pnp_deblur_plan* p, const T* x, bool conj_kernel, T alpha, T beta, const T* c, const uint8_t* sel, T* out,
          hipStream_t s) {
-    constexpr int G = 256 / NL;
+    constexpr int G = LineSmem<T, RA, LA>::G;
     const int B = p->batch;
-    int rc = col_fwd<T, NL>(p, x, B, s);
+    int rc = col_fwd<T, RA, LA>(p, x, B, s);
     if (rc) return rc;
     dim3 grid(p->n / G, B);
     cx<T>* w0 = (cx<T>*)p->w0;
     if (conj_kernel)
-        k_rowpass<T, NL, true, false><<<grid, 256, 0, s>>>(w0, w0, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big, (const cx<T>*)p->FB);
+        k_rowpass<T, RA, LA, true, false><<<grid, 256, 0, s>>>(w0, w0, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big, (const cx<T>*)p->FB);
     else
-        k_rowpass<T, NL, false, false><<<grid, 256, 0, s>>>(w0, w0, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big, (const cx<T>*)p->FB);
+        k_rowpass<T, RA, LA, false, false><<<grid, 256, 0, s>>>(w0, w0, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big, (const cx<T>*)p->FB);
     PNP_CHECK_LAUNCH();
-    k_colpass<T, NL, true, false, false, true><<<grid, 256, 0, s>>>(w0, out, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big,
+    k_colpass<T, RA, LA, true, false, false, true><<<grid, 256, 0, s>>>(w0, out, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big,
                                                                   alpha, beta, c, sel);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }
 
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 int run_grad(pnp_deblur_plan* p, const T* z, const T* Y, const uint8_t* sel, double scale, T* out, hipStream_t s) {
     const int N = p->N, B = p->batch;
     const T inv_sqrtN = (T)(1.0 / std::sqrt((double)N));           // Re ifft(.) * sqrt(N); the inverse carries 1/N
     T* res = (T*)p->r0;
     int rc;
     if (p->g_idx == nullptr) {
-        rc = blur<T, NL>(p, z, false, inv_sqrtN, (T)-1, Y, sel, res, s);        // sel o (B z - Y)
+        rc = blur<T, RA, LA>(p, z, false, inv_sqrtN, (T)-1, Y, sel, res, s);        // sel o (B z - Y)
         if (rc) return rc;
     } else {
         T* blurred = (T*)p->r1;
-        rc = blur<T, NL>(p, z, false, inv_sqrtN, (T)0, nullptr, nullptr, blurred, s);
+        rc = blur<T, RA, LA>(p, z, false, inv_sqrtN, (T)0, nullptr, nullptr, blurred, s);
         if (rc) return rc;
         T* down = (T*)p->down;
         k_gather4<T><<<dim3((p->M + 255) / 256, B), 256, 0, s>>>(blurred, p->g_idx, (const T*)p->g_w, p->M, N, (T)-1, Y, sel, down);
@@ -212,15 +224,15 @@ int run_grad(pnp_deblur_plan* p, const T* z, const T* Y, const uint8_t* sel, dou
         k_csr<T><<<dim3((N + 255) / 256, B), 256, 0, s>>>(down, p->a_rowptr, p->a_col, (const T*)p->a_val, N, p->M, res);
         PNP_CHECK_LAUNCH();
     }
-    return blur<T, NL>(p, res, true, (T)(scale / std::sqrt((double)N)), (T)0, nullptr, nullptr, out, s);
+    return blur<T, RA, LA>(p, res, true, (T)(scale / std::sqrt((double)N)), (T)0, nullptr, nullptr, out, s);
 }
 
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 int run_forward(pnp_deblur_plan* p, const T* x, T* out, hipStream_t s) {
     const T inv_sqrtN = (T)(1.0 / std::sqrt((double)p->N));
-    if (p->g_idx == nullptr) return blur<T, NL>(p, x, false, inv_sqrtN, (T)0, nullptr, nullptr, out, s);
+    if (p->g_idx == nullptr) return blur<T, RA, LA>(p, x, false, inv_sqrtN, (T)0, nullptr, nullptr, out, s);
     T* blurred = (T*)p->r1;
-    int rc = blur<T, NL>(p, x, false, inv_sqrtN, (T)0, nullptr, nullptr, blurred, s);
+    int rc = blur<T, RA, LA>(p, x, false, inv_sqrtN, (T)0, nullptr, nullptr, blurred, s);
     if (rc) return rc;
     k_gather4<T><<<dim3((p->M + 255) / 256, p->batch), 256, 0, s>>>(blurred, p->g_idx, (const T*)p->g_w, p->M, p->N, (T)0, nullptr, nullptr, out);
     PNP_CHECK_LAUNCH();
@@ -228,12 +240,12 @@ int run_forward(pnp_deblur_plan* p, const T* x, T* out, hipStream_t s) {
 }
 
 // FB = spectrum of the blur kernel in the plan's [k1][k2] order
-template <typename T, int NL>
+template <typename T, int RA, int LA>
 int make_spectrum(pnp_deblur_plan* p, hipStream_t s) {
-    constexpr int G = 256 / NL;
-    int rc = col_fwd<T, NL>(p, (const T*)p->r0, 1, s);
+    constexpr int G = LineSmem<T, RA, LA>::G;
+    int rc = col_fwd<T, RA, LA>(p, (const T*)p->r0, 1, s);
     if (rc) return rc;
-    k_rowpass<T, NL, false, true><<<dim3(p->n / G, 1), 256, 0, s>>>((const cx<T>*)p->w0, (cx<T>*)p->FB, (const cx<T>*)p->tw_line,
+    k_rowpass<T, RA, LA, false, true><<<dim3(p->n / G, 1), 256, 0, s>>>((const cx<T>*)p->w0, (cx<T>*)p->FB, (const cx<T>*)p->tw_line,
                                                                    (const cx<T>*)p->tw_big, nullptr);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
@@ -256,11 +268,11 @@ extern "C" int pnp_deblur_plan_create(pnp_deblur_plan** out, int H, int W, int b
                                       const int32_t* a_col, const void* a_val) {
     PNP_CHECK_ARG(out && Bk, "null argument");
     const int N = H * W;
-    PNP_CHECK_ARG(N == 65536 || N == 4096, "H*W must be 65536 (256x256) or 4096 (64x64)");
+    PNP_CHECK_ARG(N == 65536 || N == 16384 || N == 4096, "H*W must be 65536 (256x256), 16384 (128x128) or 4096 (64x64)");
     PNP_CHECK_ARG(dtype == PNP_F32 || dtype == PNP_F64, "bad dtype");
     PNP_CHECK_ARG(batch >= 1 && M >= 1 && M <= N, "bad batch / M");
     auto* p = new pnp_deblur_plan{};
-    p->N = N; p->n = N == 65536 ? 256 : 64; p->NL = N == 65536 ? 16 : 8; p->batch = batch; p->dtype = dtype; p->M = M;
+    p->N = N; p->n = N == 65536 ? 256 : N == 16384 ? 128 : 64; p->NL = N == 65536 ? 16 : N == 16384 ? 12 : 8; p->batch = batch; p->dtype = dtype; p->M = M;
     const size_t rs = dtype == PNP_F32 ? 4 : 8, cs = 2 * rs;
     hipError_t e = hipMalloc(&p->tw_line, p->n * cs);
     if (e == hipSuccess) e = hipMalloc(&p->tw_big, (size_t)N * cs);
@@ -298,8 +310,11 @@ extern "C" int pnp_deblur_plan_create(pnp_deblur_plan** out, int H, int W, int b
         // FB = fft(B): upload B into r0 (as problem 0), transform once
         e = hipMemcpy(p->r0, Bk, (size_t)N * rs, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            int rc = dtype == PNP_F32 ? (p->NL == 16 ? make_spectrum<float, 16>(p, 0) : make_spectrum<float, 8>(p, 0))
-                                      : (p->NL == 16 ? make_spectrum<double, 16>(p, 0) : make_spectrum<double, 8>(p, 0));
+            int rc;
+#define PNP_DB_DISPATCH(FN, ...)                                                                         \
+    (p->dtype == PNP_F32 ? (p->NL == 16 ? FN<float, 16, 16>(__VA_ARGS__) : p->NL == 12 ? FN<float, 8, 16>(__VA_ARGS__) : FN<float, 8, 8>(__VA_ARGS__)) \
+                         : (p->NL == 16 ? FN<double, 16, 16>(__VA_ARGS__) : p->NL == 12 ? FN<double, 8, 16>(__VA_ARGS__) : FN<double, 8, 8>(__VA_ARGS__)))
+            rc = PNP_DB_DISPATCH(make_spectrum, p, (hipStream_t)0);
             if (rc) e = hipErrorUnknown;
             else e = hipDeviceSynchronize();
         }
@@ -330,18 +345,28 @@ extern "C" int pnp_deblur_grad(pnp_deblur_plan* p, const void* z, const void* Y,
                                void* out, void* stream) {
     PNP_CHECK_ARG(p && z && Y && out, "null argument");
     hipStream_t s = (hipStream_t)stream;
-    if (p->dtype == PNP_F32)
-        return p->NL == 16 ? run_grad<float, 16>(p, (const float*)z, (const float*)Y, sel, scale, (float*)out, s)
-                           : run_grad<float, 8>(p, (const float*)z, (const float*)Y, sel, scale, (float*)out, s);
-    return p->NL == 16 ? run_grad<double, 16>(p, (const double*)z, (const double*)Y, sel, scale, (double*)out, s)
-                       : run_grad<double, 8>(p, (const double*)z, (const double*)Y, sel, scale, (double*)out, s);
+    if (p->dtype == PNP_F32) {
+        const float *zz = (const float*)z, *yy = (const float*)Y;
+        float* oo = (float*)out;
+        return p->NL == 16 ? run_grad<float, 16, 16>(p, zz, yy, sel, scale, oo, s)
+             : p->NL == 12 ? run_grad<float, 8, 16>(p, zz, yy, sel, scale, oo, s) : run_grad<float, 8, 8>(p, zz, yy, sel, scale, oo, s);
+    }
+    const double *zz = (const double*)z, *yy = (const double*)Y;
+    double* oo = (double*)out;
+    return p->NL == 16 ? run_grad<double, 16, 16>(p, zz, yy, sel, scale, oo, s)
+         : p->NL == 12 ? run_grad<double, 8, 16>(p, zz, yy, sel, scale, oo, s) : run_grad<double, 8, 8>(p, zz, yy, sel, scale, oo, s);
 }
 
 // forward model S B x (DeblurSR.py:110-112), for problem setup / f(w); out real [batch][M]
 extern "C" int pnp_deblur_forward(pnp_deblur_plan* p, const void* x, void* out, void* stream) {
     PNP_CHECK_ARG(p && x && out, "null argument");
     hipStream_t s = (hipStream_t)stream;
-    if (p->dtype == PNP_F32)
-        return p->NL == 16 ? run_forward<float, 16>(p, (const float*)x, (float*)out, s) : run_forward<float, 8>(p, (const float*)x, (float*)out, s);
-    return p->NL == 16 ? run_forward<double, 16>(p, (const double*)x, (double*)out, s) : run_forward<double, 8>(p, (const double*)x, (double*)out, s);
+    if (p->dtype == PNP_F32) {
+        const float* xx = (const float*)x;
+        float* oo = (float*)out;
+        return p->NL == 16 ? run_forward<float, 16, 16>(p, xx, oo, s) : p->NL == 12 ? run_forward<float, 8, 16>(p, xx, oo, s) : run_forward<float, 8, 8>(p, xx, oo, s);
+    }
+    const double* xx = (const double*)x;
+    double* oo = (double*)out;
+    return p->NL == 16 ? run_forward<double, 16, 16>(p, xx, oo, s) : p->NL == 12 ? run_forward<double, 8, 16>(p, xx, oo, s) : run_forward<double, 8, 8>(p, xx, oo, s);
 }

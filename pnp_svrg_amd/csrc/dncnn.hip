@@ -26,6 +26,7 @@
 //   * per wave and phase: 576 MFMAs (64 cycles each) vs 576 ds_read_b32 + 43 global loads: the
 //     matrix pipe is the only busy resource by a wide margin.
 #include "common.h"
+#include "reduce.h"
 #include <vector>
 #include <algorithm>
 #include <cstdlib>
@@ -518,27 +519,6 @@ __global__ void k_sum_parts(const double* __restrict__ part, int nparts, double*
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_minmax2(const T* __restrict__ z, int n, T* __restrict__ out) {
-    __shared__ T rmin[4], rmax[4];
-    const size_t base = (size_t)blockIdx.x * n;
-    T lo = z[base], hi = lo;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const T v = z[base + i];
-        lo = v < lo ? v : lo;
-        hi = v > hi ? v : hi;
-    }
-    lo = wave_min(lo);
-    hi = wave_max(hi);
-    if ((threadIdx.x & 63) == 0) { rmin[threadIdx.x >> 6] = lo; rmax[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; ++i) { lo = rmin[i] < lo ? rmin[i] : lo; hi = rmax[i] > hi ? rmax[i] : hi; }
-        out[2 * blockIdx.x] = lo;
-        out[2 * blockIdx.x + 1] = hi;
-    }
-}
-
 }  // namespace pnp
 
 using namespace pnp;
@@ -647,7 +627,7 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     T* mm = normalise ? (T*)p->mm : nullptr;             // raw network (no wrapper scaling): lo = 0, hi = 1
     double srange = 1.0, sshift = 0.0;
     if (normalise) {
-        k_minmax2<T><<<B, 256, 0, s>>>(z_in, HW, mm);
+        k_minmax<T><<<B, 256, 0, s>>>(z_in, HW, mm);
         PNP_CHECK_LAUNCH();
         srange = 1.0 + sigma_net / 255.0 / 2.0;
         sshift = (1.0 - srange) / 2.0;

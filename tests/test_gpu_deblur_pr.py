@@ -122,3 +122,20 @@ def test_phase_retrieval(g_pr, dtype):
         np.testing.assert_allclose(r['z'], g['pr_svrg_z'], rtol=0, atol=1e-8)
     else:
         assert np.abs(ps - g['pr_svrg_psnr']).max() <= 0.01 + 1e-9
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('scale', [100, 50])
+def test_deblur_128_vs_oracle(dtype, scale):
+    """128 x 128 (rectangular 8 x 16 FFT split, N = 16384): gradients against the golden-pinned oracle."""
+    import problems
+    np.random.seed(0)
+    p = problems.Deblur(IMG256, H=128, W=128, kernel='Minimal', scale_percent=scale, snr=10., dtype=dtype)
+    np.random.seed(0)
+    po = op.Deblur(IMG256, H=128, W=128, kernel='Minimal', scale_percent=scale, snr=10.)
+    assert p.M == po.M
+    np.random.seed(3)
+    mb = p.select_mb(p.M // 5)
+    rel = 1e-10 if dtype == torch.float64 else 3e-4
+    for got, ref in ((p.grad_full(po.Xinit), po.grad_full(po.Xinit)), (p.grad_stoch(po.Xinit, mb), po.grad_stoch(po.Xinit, mb))):
+        assert np.abs(got - ref).max() <= rel * np.abs(ref).max()

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo + PNP_BENCH_ONE_DEVICE=1 rehearses the N>1 path with all ranks on GPU 0')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay one outer iteration (T2 steps) per hipGraph launch; --steps/--warmup are rounded up to multiples of T2')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
     return ap.parse_args()
 
@@ -132,14 +134,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for s in range(a.warmup):
-        eng.step(idx[s % n_draw] if idx is not None else None)
+    if a.graph:
+        assert idx is None, '--graph needs device-side minibatch draws'
+        a.steps = -(-a.steps // T2) * T2
+        a.warmup = -(-max(a.warmup, 1) // T2) * T2
+        eng.capture()
+        eng.run_outer(a.warmup // T2)
+    else:
+        for s in range(a.warmup):
+            eng.step(idx[s % n_draw] if idx is not None else None)
     sync_all()
-    if a.workload == 'dncnn':
+    if a.workload == 'dncnn' and not a.graph:
         prox.plan.profile_begin(a.steps + 8)
     t0 = time.perf_counter()
-    for s in range(a.steps):
-        eng.step(idx[(a.warmup + s) % n_draw] if idx is not None else None)
+    if a.graph:
+        eng.run_outer(a.steps // T2)
+    else:
+        for s in range(a.steps):
+            eng.step(idx[(a.warmup + s) % n_draw] if idx is not None else None)
     sync_all()
     dt = time.perf_counter() - t0
     cdev = 'cuda' if (dist is None or a.backend == 'nccl') else 'cpu'      # where collective buffers live
@@ -149,7 +161,7 @@ def main():
         dt = float(t.item())
 
     roofline = None
-    if a.workload == 'dncnn':
+    if a.workload == 'dncnn' and not a.graph:
         ms, launches = prox.plan.profile_end()
         flops = FLOP_MID_PER_IMAGE * B
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

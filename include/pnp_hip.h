@@ -46,9 +46,10 @@ int pnp_csmri_sel_from_indices(pnp_csmri_plan* plan, const int32_t* idx, int n, 
 /* Device-side minibatch draw (problems/CSMRI.py:66-74 semantics: `mb` of the M0 sampled locations, uniform
  * without replacement) straight into the transposed selector: counter-based keys hash(seed, step, problem,
  * position), the mb smallest win (radix select).  mask_idx: [batch][M0] int32 = flatnonzero(mask) per problem.
- * Deterministic in (seed, step); NOT NumPy's legacy stream (reference-identical draws come from the host). */
+ * Deterministic in (seed, step); NOT NumPy's legacy stream (reference-identical draws come from the host).
+ * step_dev (may be NULL): device-resident counter added to `step`, so the call can be replayed from a hipGraph. */
 int pnp_csmri_draw_minibatch(pnp_csmri_plan* plan, const int32_t* mask_idx, int M0, int mb, uint64_t seed,
-                             uint32_t step, uint8_t* selT, void* stream);
+                             uint32_t step, const uint32_t* step_dev, uint8_t* selT, void* stream);
 /* Same, from a dense row-major 0/1 indicator [batch][H][W] (uint8).                      */
 int pnp_csmri_sel_from_dense(pnp_csmri_plan* plan, const uint8_t* sel, uint8_t* selT, void* stream);
 
@@ -161,6 +162,11 @@ int pnp_dncnn_profile_end(pnp_dncnn_plan* plan, double* avg_ms_per_launch, long*
 /* Diagnostic (allocates + synchronises; never on the hot path): median in-kernel shader cycles and 100 MHz
  * reference ticks of the conv tile loop after `reps` back-to-back launches -> the clock held under load. */
 int pnp_dncnn_debug_clock(pnp_dncnn_plan* plan, int reps, double* cycles, double* ref_ticks, void* stream);
+
+/* Device-resident step counter and log ring (hipGraph replay of a whole outer iteration: nothing in the graph
+ * depends on a host-side step index).  pnp_log_append: log[(*step_dev % n_log)][0..n) = src[0..n).        */
+int pnp_counter_add(uint32_t* counter, uint32_t inc, void* stream);
+int pnp_log_append(const double* src, int n, double* log, int n_log, const uint32_t* step_dev, void* stream);
 
 /* ------------------------------------------------------------------ elementwise
  * out = a*x + b*y + c*w   (y, w may be NULL); n = total element count.

@@ -252,7 +252,9 @@ __device__ __forceinline__ uint32_t mb_hash(uint64_t seed, uint32_t step, uint32
 }
 
 __global__ __launch_bounds__(1024) void k_draw_mb(const int32_t* __restrict__ mask_idx, int M0, int mb, uint64_t seed,
-                                                  uint32_t step, uint8_t* __restrict__ selT, int H, int W) {
+                                                  uint32_t step, const uint32_t* __restrict__ step_dev,
+                                                  uint8_t* __restrict__ selT, int H, int W) {
+    if (step_dev != nullptr) step += *step_dev;                  // device-resident counter (hipGraph replays)
     __shared__ int hist[256];
     __shared__ int s_bin, s_before, s_ntie;
     __shared__ int tie[64];
@@ -389,10 +391,10 @@ extern "C" int pnp_csmri_sel_from_indices(pnp_csmri_plan* p, const int32_t* idx,
 }
 
 extern "C" int pnp_csmri_draw_minibatch(pnp_csmri_plan* p, const int32_t* mask_idx, int M0, int mb, uint64_t seed,
-                                        uint32_t step, uint8_t* selT, void* stream) {
+                                        uint32_t step, const uint32_t* step_dev, uint8_t* selT, void* stream) {
     PNP_CHECK_ARG(p && mask_idx && selT, "null argument");
     PNP_CHECK_ARG(M0 >= 1 && M0 <= p->H * p->W && mb >= 1 && mb <= M0, "need 1 <= mb <= M0 <= H*W");
-    k_draw_mb<<<p->batch, 1024, 0, (hipStream_t)stream>>>(mask_idx, M0, mb, seed, step, selT, p->H, p->W);
+    k_draw_mb<<<p->batch, 1024, 0, (hipStream_t)stream>>>(mask_idx, M0, mb, seed, step, step_dev, selT, p->H, p->W);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }

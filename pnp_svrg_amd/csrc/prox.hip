@@ -304,6 +304,29 @@ extern "C" int pnp_minmax(const void* z, int n, int batch, int dtype, void* out,
     return PNP_OK;
 }
 
+// ---- device-resident step counter + log ring: what lets a whole outer iteration be captured in a hipGraph
+__global__ void k_counter_add(uint32_t* ctr, uint32_t inc) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += inc; }
+
+__global__ void k_log_append(const double* __restrict__ src, int n, double* __restrict__ log, int n_log,
+                             const uint32_t* __restrict__ step_dev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) log[(size_t)(*step_dev % (uint32_t)n_log) * n + i] = src[i];
+}
+
+extern "C" int pnp_counter_add(uint32_t* counter, uint32_t inc, void* stream) {
+    PNP_CHECK_ARG(counter != nullptr, "null counter");
+    k_counter_add<<<1, 64, 0, (hipStream_t)stream>>>(counter, inc);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+
+extern "C" int pnp_log_append(const double* src, int n, double* log, int n_log, const uint32_t* step_dev, void* stream) {
+    PNP_CHECK_ARG(src && log && step_dev && n >= 1 && n_log >= 1, "bad argument");
+    k_log_append<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(src, n, log, n_log, step_dev);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+
 extern "C" int pnp_axpbypcz(double a, const void* x, double b, const void* y, double c, const void* w, void* out,
                             size_t n, int dtype, void* stream) {
     PNP_CHECK_ARG(x && out, "null argument");

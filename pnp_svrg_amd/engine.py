@@ -133,10 +133,16 @@ class SvrgEngine:
         self.seed = seed
         prox.bind(batch)
         self.s = 0
+        # device-resident step counter (mirrors self.s) and scratch row: a whole outer iteration can then be
+        # captured once in a hipGraph and replayed (no host-side step index inside the graph)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sse_tmp = torch.zeros(batch.B, dtype=torch.float64, device=dev)
+        self.graph = None
 
     def reset(self):
         self.z.copy_(self.b.xinit)
         self.s = 0
+        self.step_dev.zero_()
         if hasattr(self.prox, 't'):
             self.prox.t = 0
 
@@ -158,7 +164,54 @@ class SvrgEngine:
         else:
             ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
         self.prox(self.z, b.xrec, self.sse_log[s % self.n_log])
+        ops.counter_add(self.step_dev, 1)
         self.s += 1
+
+    # ---- hipGraph form: one OUTER iteration (full-gradient refresh + T2 inner iterations) = one graph launch
+    def _outer_body(self):
+        b = self.b
+        b.plan.grad(self.z, b.maskT, yh=b.yh_full, alpha=1.0 / float(b.M0[0]), out=self.mu)
+        self.w.copy_(self.z)
+        lr = self.eta
+        for _ in range(self.T2):
+            if self.variant == 'svrg':
+                b.plan.draw_minibatch(b.mask_idx, self.mb, self.seed, 0, out=self.selT, step_dev=self.step_dev)
+                b.plan.grad(self.z, self.selT, b=self.w, alpha=-lr / self.mb, beta=1.0, c1=self.z, gamma=-lr, c2=self.mu, out=self.z)
+            else:
+                ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
+            self.prox(self.z, b.xrec, self.sse_tmp)
+            ops.log_append(self.sse_tmp, self.sse_log, self.step_dev)
+            ops.counter_add(self.step_dev, 1)
+
+    def capture(self):
+        """Capture one outer iteration into a hipGraph (torch.cuda.CUDAGraph on ROCm).  Needs lr_decay == 1, a
+        step count that is a multiple of T2, device-side minibatch draws and a prox without host-side
+        per-call state (TVProx with denoise_strength == 0, DnCNNProx).  State is left untouched."""
+        assert self.lr_decay == 1.0 and self.s % self.T2 == 0
+        assert getattr(self.prox, 'denoise_strength', 0.0) == 0.0
+        keep = (self.z.clone(), self.w.clone(), self.mu.clone(), self.sse_log.clone(), self.step_dev.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._outer_body()                                  # warm-up outside capture (lazy module loads)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._outer_body()
+        torch.cuda.synchronize()
+        for dst, src in zip((self.z, self.w, self.mu, self.sse_log, self.step_dev), keep):
+            dst.copy_(src)
+        self.graph = g
+        return g
+
+    def run_outer(self, n_outer=1):
+        """n_outer graph replays = n_outer * T2 inner iterations."""
+        if self.graph is None:
+            self.capture()
+        for _ in range(n_outer):
+            self.graph.replay()
+            self.s += self.T2
 
     def psnr_trace(self):
         """[steps][B] PSNR (rounded to 0.01 dB like problems/problem.py:33-35), read back once."""

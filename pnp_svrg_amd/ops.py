@@ -50,13 +50,13 @@ class CsmriPlan:
         N.call('pnp_csmri_sel_from_indices', self._h, _p(idx), idx.shape[1], _p(out), _stream())
         return out
 
-    def draw_minibatch(self, mask_idx, mb, seed, step, out=None):
+    def draw_minibatch(self, mask_idx, mb, seed, step, out=None, step_dev=None):
         """Device-side uniform draw of `mb` of each problem's sampled locations -> transposed selector.
         mask_idx: int32 [B, M0] (flatnonzero(mask) per problem)."""
         assert mask_idx.dtype == torch.int32 and mask_idx.shape[0] == self.B
         out = out if out is not None else torch.empty((self.B, self.W, self.H), dtype=torch.uint8, device=mask_idx.device)
         N.call('pnp_csmri_draw_minibatch', self._h, _p(mask_idx), mask_idx.shape[1], int(mb), int(seed) & (2 ** 64 - 1),
-               int(step) & 0xFFFFFFFF, _p(out), _stream())
+               int(step) & 0xFFFFFFFF, _p(step_dev), _p(out), _stream())
         return out
 
     def sel_from_dense(self, sel, out=None):
@@ -279,3 +279,15 @@ def pr_grad(A, w, y, rows=None, scale=1.0, workspace=None, out=None):
     nsel = M if rows is None else rows.numel()
     N.call('pnp_pr_grad', _p(A), _p(w), _p(y), _p(rows), nsel, M, Nn, _DT[A.dtype], float(scale), _p(workspace), _p(out), _stream())
     return out
+
+
+def counter_add(counter, inc=1):
+    """counter: int32 device tensor with one element (device-resident step counter)."""
+    require_gpu()
+    N.call('pnp_counter_add', _p(counter), int(inc), _stream())
+
+
+def log_append(src, log, step_dev):
+    """log[(step % n_log)] = src; src: float64 [n], log: float64 [n_log, n], step_dev: device counter."""
+    require_gpu()
+    N.call('pnp_log_append', _p(src), src.numel(), _p(log), log.shape[0], _p(step_dev), _stream())

@@ -144,7 +144,8 @@ int pnp_dncnn_plan_create(pnp_dncnn_plan** plan, int n_mid, const float* w_first
                           const float* b_mid, const float* w_last, int H, int W, int batch);
 int pnp_dncnn_plan_destroy(pnp_dncnn_plan* plan);
 /* Conv kernel choice for the 64->64 layers: 1 = Winograd F(2,3) along x (default; fp32, executes 2/3 of the
- * multiply-adds), 0 = direct implicit GEMM (bit-for-bit an fmaf chain).  Default comes from the environment
+ * multiply-adds), 0 = direct implicit GEMM (bit-for-bit an fmaf chain), 2 = Winograd with two workgroups per CU
+ * (4-row tiles, per-phase weight re-fetch; same throughput, kept as a documented experiment; needs H % 4 == 0).  Default comes from the environment
  * variable PNP_DNCNN_WINOGRAD (unset = 1) at plan creation.                                       */
 int pnp_dncnn_set_winograd(pnp_dncnn_plan* plan, int enable);
 /* raw network: r = net(x), x and r [batch][H][W] fp32 (the predicted noise residual)          */

@@ -113,7 +113,7 @@ class DncnnPlan:
                w_last.ctypes.data_as(ctypes.c_void_p), H, W, batch)
         self._h = h
         if winograd is not None:
-            N.call('pnp_dncnn_set_winograd', self._h, 1 if winograd else 0)
+            N.call('pnp_dncnn_set_winograd', self._h, int(winograd))   # 0 direct, 1 Winograd, 2 Winograd two-WG/CU
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None

@@ -2,8 +2,10 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from pnp_svrg_amd import ops
 W = dict(np.load('/root/repo/tests/golden/dncnn_noise15.npz'))
+import os
+mode = int(os.environ.get('WINO', '1'))
 for B in (1, 4, 16):
-    plan = ops.DncnnPlan(W, 256, 256, B)
+    plan = ops.DncnnPlan(W, 256, 256, B, winograd=mode)
     x = torch.rand(B, 256, 256, device='cuda')
     out = torch.empty_like(x)
     for _ in range(3): plan.forward(x, out)

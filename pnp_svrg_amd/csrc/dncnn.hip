@@ -240,6 +240,39 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
 // The B-operand transform (4 LDS values -> 4 V values, 4 VALU ops) feeds up to 12 MFMAs.
 constexpr int WINO_U = 2 * (HALF_C / 4) * 3 * 4;      // 192 transformed-weight registers per wave
 struct __attribute__((packed, aligned(4))) f2u { float a, b; };   // 4-byte-aligned float pair
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// The raw Winograd inputs of one group -- 5 halo rows x (d0,d1),(d2,d3) -- as ten hand-issued ds_read2_b32 off ONE
+// base register with immediate offsets (row stride PC = 40 dwords).  hipcc pairs these loads as (d0,d3),(d1,d2)
+// with a second base register and an extra v_add per row, and every VALU instruction here costs matrix-pipe issue.
+// The results are asynchronous: the caller waits lgkmcnt(0) (wino_lds_wait) before the first use.
+__device__ __forceinline__ void wino_lds_load(float (&dd)[5][4], unsigned lds_byte_addr) {
+    f32x2v r0, r1, r2, r3, r4, r5, r6, r7, r8, r9;
+    asm volatile(
+        "ds_read2_b32 %0, %10 offset0:0 offset1:1\n"
+        "ds_read2_b32 %1, %10 offset0:2 offset1:3\n"
+        "ds_read2_b32 %2, %10 offset0:40 offset1:41\n"
+        "ds_read2_b32 %3, %10 offset0:42 offset1:43\n"
+        "ds_read2_b32 %4, %10 offset0:80 offset1:81\n"
+        "ds_read2_b32 %5, %10 offset0:82 offset1:83\n"
+        "ds_read2_b32 %6, %10 offset0:120 offset1:121\n"
+        "ds_read2_b32 %7, %10 offset0:122 offset1:123\n"
+        "ds_read2_b32 %8, %10 offset0:160 offset1:161\n"
+        "ds_read2_b32 %9, %10 offset0:162 offset1:163\n"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9)
+        : "v"(lds_byte_addr)
+        : "memory");
+    dd[0][0] = r0.x; dd[0][1] = r0.y; dd[0][2] = r1.x; dd[0][3] = r1.y;
+    dd[1][0] = r2.x; dd[1][1] = r2.y; dd[1][2] = r3.x; dd[1][3] = r3.y;
+    dd[2][0] = r4.x; dd[2][1] = r4.y; dd[2][2] = r5.x; dd[2][3] = r5.y;
+    dd[3][0] = r6.x; dd[3][1] = r6.y; dd[3][2] = r7.x; dd[3][3] = r7.y;
+    dd[4][0] = r8.x; dd[4][1] = r8.y; dd[4][2] = r9.x; dd[4][3] = r9.y;
+}
+__device__ __forceinline__ void wino_lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+static_assert(PC == 40, "wino_lds_load hard-codes the 40-dword LDS row stride");
 
 template <bool RELU, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ in, float* __restrict__ out,
@@ -310,24 +343,15 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
             // group = (channel quad c4, block of 5 halo rows): 10 ds_read2 + 20 transform ops + 48 MFMAs
             constexpr int NG = (HALF_C / 4) * 2;               // 16 groups per half
             float d[2][5][4];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                // two 4-byte-aligned pair loads (d0,d1), (d2,d3): one ds_read2_b32 each off ONE base register
-                const f2u lo = *reinterpret_cast<const f2u*>(xb + i * PC), hi = *reinterpret_cast<const f2u*>(xb + i * PC + 2);
-                d[0][i][0] = lo.a; d[0][i][1] = lo.b; d[0][i][2] = hi.a; d[0][i][3] = hi.b;
-            }
+            const unsigned xb_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + 4u * (unsigned)xb_off;
+            wino_lds_load(d[0], xb_addr);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int c4 = g / 2, rb = g % 2;
+                wino_lds_wait();                                // d[g & 1] has landed
                 if (g + 1 < NG) {
                     const int c4n = (g + 1) / 2, rbn = (g + 1) % 2;
-                    // one base per group (a plane is 400 dwords, ds_read2 offsets reach 255): 1 v_add, 10 ds_read2
-                    const float* gb = xb + (4 * c4n) * PLANE + (5 * rbn) * PC;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        const f2u lo = *reinterpret_cast<const f2u*>(gb + i * PC), hi = *reinterpret_cast<const f2u*>(gb + i * PC + 2);
-                        d[(g + 1) & 1][i][0] = lo.a; d[(g + 1) & 1][i][1] = lo.b; d[(g + 1) & 1][i][2] = hi.a; d[(g + 1) & 1][i][3] = hi.b;
-                    }
+                    wino_lds_load(d[(g + 1) & 1], xb_addr + 4u * ((4 * c4n) * PLANE + (5 * rbn) * PC));
                 }
                 if (g < PIECES_PER_WAVE) {
                     const int pc = wv + 4 * g;
@@ -353,12 +377,6 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                         }
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 10; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_compute += t - tp; tp = t; }

@@ -246,7 +246,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // base register with immediate offsets (row stride PC = 40 dwords).  hipcc pairs these loads as (d0,d3),(d1,d2)
 // with a second base register and an extra v_add per row, and every VALU instruction here costs matrix-pipe issue.
 // The results are asynchronous: the caller waits lgkmcnt(0) (wino_lds_wait) before the first use.
-__device__ __forceinline__ void wino_lds_load(float (&dd)[5][4], unsigned lds_byte_addr) {
+__device__ __forceinline__ void wino_lds_load(f32x2v (&dd)[5][2], unsigned lds_byte_addr) {
     f32x2v r0, r1, r2, r3, r4, r5, r6, r7, r8, r9;
     asm volatile(
         "ds_read2_b32 %0, %10 offset0:0 offset1:1\n"
@@ -262,14 +262,16 @@ __device__ __forceinline__ void wino_lds_load(float (&dd)[5][4], unsigned lds_by
         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8), "=&v"(r9)
         : "v"(lds_byte_addr)
         : "memory");
-    dd[0][0] = r0.x; dd[0][1] = r0.y; dd[0][2] = r1.x; dd[0][3] = r1.y;
-    dd[1][0] = r2.x; dd[1][1] = r2.y; dd[1][2] = r3.x; dd[1][3] = r3.y;
-    dd[2][0] = r4.x; dd[2][1] = r4.y; dd[2][2] = r5.x; dd[2][3] = r5.y;
-    dd[3][0] = r6.x; dd[3][1] = r6.y; dd[3][2] = r7.x; dd[3][3] = r7.y;
-    dd[4][0] = r8.x; dd[4][1] = r8.y; dd[4][2] = r9.x; dd[4][3] = r9.y;
+    dd[0][0] = r0; dd[0][1] = r1; dd[1][0] = r2; dd[1][1] = r3; dd[2][0] = r4; dd[2][1] = r5;
+    dd[3][0] = r6; dd[3][1] = r7; dd[4][0] = r8; dd[4][1] = r9;
 }
-__device__ __forceinline__ void wino_lds_wait() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+// The wait takes the ten register pairs as in/out operands, so every consumer is data-dependent on it and no pass
+// can move a use of the (still in flight) load results above the s_waitcnt.
+__device__ __forceinline__ void wino_lds_wait(f32x2v (&dd)[5][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(dd[0][0]), "+v"(dd[0][1]), "+v"(dd[1][0]), "+v"(dd[1][1]), "+v"(dd[2][0]), "+v"(dd[2][1]),
+                   "+v"(dd[3][0]), "+v"(dd[3][1]), "+v"(dd[4][0]), "+v"(dd[4][1])
+                 :: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 static_assert(PC == 40, "wino_lds_load hard-codes the 40-dword LDS row stride");
@@ -342,13 +344,13 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
 
             // group = (channel quad c4, block of 5 halo rows): 10 ds_read2 + 20 transform ops + 48 MFMAs
             constexpr int NG = (HALF_C / 4) * 2;               // 16 groups per half
-            float d[2][5][4];
+            f32x2v d[2][5][2];
             const unsigned xb_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + 4u * (unsigned)xb_off;
             wino_lds_load(d[0], xb_addr);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int c4 = g / 2, rb = g % 2;
-                wino_lds_wait();                                // d[g & 1] has landed
+                wino_lds_wait(d[g & 1]);                        // d[g & 1] has landed
                 if (g + 1 < NG) {
                     const int c4n = (g + 1) / 2, rbn = (g + 1) % 2;
                     wino_lds_load(d[(g + 1) & 1], xb_addr + 4u * ((4 * c4n) * PLANE + (5 * rbn) * PC));
@@ -364,8 +366,13 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const int ry = 5 * rb + i;
-                    const float d0 = d[g & 1][i][0], d1 = d[g & 1][i][1], d2 = d[g & 1][i][2], d3 = d[g & 1][i][3];
-                    const float V[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+                    // B^T d as two packed-f32 ops: (d0-d2, -d1-d2) and (d1-d2, d1-d3).  The middle two components are
+                    // the NEGATED textbook ones (d1+d2, d2-d1); the inverse transform below flips their signs back.
+                    const f32x2v A = d[g & 1][i][0], Bq = d[g & 1][i][1];
+                    f32x2v v01;                                 // hipcc lowers this shuffle+negate to movs + two adds: spell it
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]\n\ts_nop 1" : "=v"(v01) : "v"(A), "v"(Bq));
+                    const f32x2v v23 = f32x2v{A.y, A.y} - Bq;
+                    const float V[4] = {v01.x, v01.y, v23.x, v23.y};
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const int r = ry - dy;
@@ -392,8 +399,8 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
             for (int q = 0; q < 4; ++q) {
                 const float m0 = acc[r][0][q], m1 = acc[r][1][q], m2 = acc[r][2][q], m3 = acc[r][3][q];
                 float2 v;
-                v.x = (m0 + m1 + m2) + bv[q];
-                v.y = (m1 - m2 - m3) + bv[q];
+                v.x = (m0 - m1 - m2) + bv[q];                   // m1, m2 carry the flipped signs of the packed transform
+                v.y = (m2 - m1 - m3) + bv[q];
                 if (RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; }
                 *reinterpret_cast<float2*>(ob + loff[q] + r * W) = v;
             }

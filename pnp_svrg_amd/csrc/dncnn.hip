@@ -369,7 +369,10 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                     // B^T d as two packed-f32 ops: (d0-d2, -d1-d2) and (d1-d2, d1-d3).  The middle two components are
                     // the NEGATED textbook ones (d1+d2, d2-d1); the inverse transform below flips their signs back.
                     const f32x2v A = d[g & 1][i][0], Bq = d[g & 1][i][1];
-                    f32x2v v01;                                 // hipcc lowers this shuffle+negate to movs + two adds: spell it
+                    // hipcc lowers this shuffle+negate to movs + two adds, so it is spelled out.  The s_nop is REQUIRED:
+                    // a VALU write needs wait states before an MFMA reads it, and the hazard recognizer does not
+                    // look inside inline asm (without it the forward pass returns garbage -- measured).
+                    f32x2v v01;
                     asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]\n\ts_nop 1" : "=v"(v01) : "v"(A), "v"(Bq));
                     const f32x2v v23 = f32x2v{A.y, A.y} - Bq;
                     const float V[4] = {v01.x, v01.y, v23.x, v23.y};

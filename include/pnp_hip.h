@@ -143,6 +143,10 @@ typedef struct pnp_dncnn_plan pnp_dncnn_plan;
 int pnp_dncnn_plan_create(pnp_dncnn_plan** plan, int n_mid, const float* w_first, const float* w_mid,
                           const float* b_mid, const float* w_last, int H, int W, int batch);
 int pnp_dncnn_plan_destroy(pnp_dncnn_plan* plan);
+/* Biases of the first / last layer and the activation, for networks of the same 3x3-conv shape that are not
+ * bias-free ReLU nets: the MMO `simple_CNN` (denoisers/MMODenoise.py:73-101: every conv has a bias, LeakyReLU(0.01),
+ * b_mid goes in through plan_create).  b_first: HOST [64] or NULL (= zeros); negative_slope 0 = ReLU.         */
+int pnp_dncnn_set_affine(pnp_dncnn_plan* plan, const float* b_first, float b_last, float negative_slope);
 /* Conv kernel choice for the 64->64 layers: 1 = Winograd F(2,3) along x (default; fp32, executes 2/3 of the
  * multiply-adds), 0 = direct implicit GEMM (bit-for-bit an fmaf chain), 2 = Winograd with two workgroups per CU
  * (4-row tiles, per-phase weight re-fetch; same throughput, kept as a documented experiment; needs H % 4 == 0).  Default comes from the environment
@@ -154,6 +158,13 @@ int pnp_dncnn_forward(pnp_dncnn_plan* plan, const float* x, float* r, void* stre
  * z_in/z_out/xrec in `dtype` (may alias); sse_out [batch] double = sum (xrec - z_out)^2 or NULL. */
 int pnp_dncnn_denoise(pnp_dncnn_plan* plan, const void* z_in, void* z_out, int dtype, double sigma_net,
                       const void* xrec, double* sse_out, void* stream);
+
+/* MMODenoiser.denoise (denoisers/MMODenoise.py:122-128 around apply_model :18-40 and simple_CNN.forward :88-101):
+ * z_out = clip(xc + net(xc), 0, 1) with xc = clip(z_in, 0, 1) in fp32.  The reference feeds the TRANSPOSED image
+ * (np.moveaxis on a 2-D array); the caller gets the same result by creating the plan with every 3x3 kernel
+ * transposed (conv(x^T, w)^T == conv(x, w^T)).  z_in/z_out/xrec in `dtype`; sse_out as in pnp_dncnn_denoise.  */
+int pnp_mmo_denoise(pnp_dncnn_plan* plan, const void* z_in, void* z_out, int dtype, const void* xrec,
+                    double* sse_out, void* stream);
 
 /* In-band timing of the MFMA conv launches (measurement aid for bench.py): between begin and end
  * every forward/denoise call brackets its n_mid conv launches with hipEvents on the caller's

@@ -244,3 +244,37 @@ class DnCNNDenoiser:
         x = x - r
         x = (x - scale_shift) / scale_range
         return x * (hi - lo) + lo
+
+
+def mmo_forward(weights, x):
+    """`simple_CNN.forward` of reference denoisers/MMODenoise.py:88-101 (depth-n conv stack with biases, LeakyReLU
+    after all but the last conv, input added to the output).  x: 2-D float32 array."""
+    import torch
+    import torch.nn.functional as F
+    n_layers = int(weights['n_layers'])
+    slope = float(weights['negative_slope'])
+    x_in = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None, None]
+    t = x_in
+    with torch.no_grad():
+        for i in range(n_layers):
+            t = F.conv2d(t, torch.from_numpy(weights[f'conv{i}.weight']), torch.from_numpy(weights[f'conv{i}.bias']), padding=1)
+            if i < n_layers - 1:
+                t = F.leaky_relu(t, slope)
+        t = t + x_in
+    return t[0, 0].numpy()
+
+
+class MMODenoiser:
+    """reference denoisers/MMODenoise.py:122-128 around apply_model (:18-40): the network sees the TRANSPOSED image
+    (np.moveaxis(noisy, -1, 0) on a 2-D array), clamped to [0, 1] in fp32; the output is clamped, transposed back
+    and clipped.  Returns float32 like the reference."""
+
+    def __init__(self, weights):
+        self.t = 0
+        self.weights = weights
+
+    def denoise(self, noisy, sigma_est=0):
+        self.t += 1
+        xt = np.clip(np.moveaxis(np.asarray(noisy), -1, 0).astype(np.float32), 0.0, 1.0)
+        y = np.clip(mmo_forward(self.weights, xt), 0.0, 1.0)
+        return np.clip(np.moveaxis(y, 0, -1), 0.0, 1.0)

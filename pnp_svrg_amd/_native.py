@@ -41,9 +41,11 @@ SIGNATURES = {
     'pnp_minmax': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'pnp_dncnn_plan_create': (_i, [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _i, _i, _i]),
     'pnp_dncnn_plan_destroy': (_i, [_vp]),
+    'pnp_dncnn_set_affine': (_i, [_vp, _vp, ctypes.c_float, ctypes.c_float]),
     'pnp_dncnn_set_winograd': (_i, [_vp, _i]),
     'pnp_dncnn_forward': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_dncnn_denoise': (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    'pnp_mmo_denoise': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'pnp_dncnn_profile_begin': (_i, [_vp, _i]),
     'pnp_dncnn_profile_end': (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(ctypes.c_long)]),
     'pnp_dncnn_debug_clock': (_i, [_vp, _i, ctypes.POINTER(_d), ctypes.POINTER(_d), _vp]),

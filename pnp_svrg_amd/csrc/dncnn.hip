@@ -83,11 +83,12 @@ __device__ __forceinline__ void dma_half(const float* __restrict__ in, const flo
 
 // STAMP / ABL: diagnostic builds only (pnp_dncnn_debug_clock): s_memtime / s_memrealtime around the tile
 // loop and its phases; ABL bit 0 replaces the LDS reads by register values, bit 1 drops the DMA.
-template <bool RELU, bool STAMP = false, int ABL = 0>
+// LEAKY: the activation is LeakyReLU(slope) instead of ReLU (the MMO network, reference denoisers/MMODenoise.py:84).
+template <bool RELU, bool STAMP = false, int ABL = 0, bool LEAKY = false>
 __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, float* __restrict__ out,
                                                 const float* __restrict__ wpack, const float* __restrict__ bias,
                                                 const float* __restrict__ zeros, int H, int W, int ntiles,
-                                                unsigned long long* __restrict__ stamps = nullptr) {
+                                                unsigned long long* __restrict__ stamps = nullptr, float slope = 0.f) {
     __shared__ float lds[2 * HALF_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[m][r] + bv[r];
-                if (RELU) v = v > 0.f ? v : 0.f;
+                if (RELU) v = v > 0.f ? v : (LEAKY ? slope * v : 0.f);
                 ob[loff[r] + so] = v;
             }
         }
@@ -276,11 +277,11 @@ __device__ __forceinline__ void wino_lds_wait(f32x2v (&dd)[5][2]) {
 }
 static_assert(PC == 40, "wino_lds_load hard-codes the 40-dword LDS row stride");
 
-template <bool RELU, bool STAMP = false>
+template <bool RELU, bool STAMP = false, bool LEAKY = false>
 __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ in, float* __restrict__ out,
                                                      const float* __restrict__ upack, const float* __restrict__ bias,
                                                      const float* __restrict__ zeros, int H, int W, int ntiles,
-                                                     unsigned long long* __restrict__ stamps = nullptr) {
+                                                     unsigned long long* __restrict__ stamps = nullptr, float slope = 0.f) {
     __shared__ float lds[2 * HALF_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                 float2 v;
                 v.x = (m0 - m1 - m2) + bv[q];                   // m1, m2 carry the flipped signs of the packed transform
                 v.y = (m2 - m1 - m3) + bv[q];
-                if (RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; }
+                if (RELU) { v.x = v.x > 0.f ? v.x : (LEAKY ? slope * v.x : 0.f); v.y = v.y > 0.f ? v.y : (LEAKY ? slope * v.y : 0.f); }
                 *reinterpret_cast<float2*>(ob + loff[q] + r * W) = v;
             }
         }
@@ -584,12 +585,16 @@ __global__ __launch_bounds__(256, 2) void k_mid_wino2(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------- first layer
 // xt = ((z - lo) / (hi - lo)) * srange + sshift ; act[c] = relu(sum_t w[c][t] * xt[tap t])
+// MMO form (clamp01): xt = clamp(z, 0, 1); act[c] = leaky_relu(b[c] + sum_t ..., slope)   (MMODenoise.py:30,90-91)
 template <typename T>
 __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T* __restrict__ mm,
-                                               const float* __restrict__ w, float* __restrict__ out,
-                                               int H, int W, double srange, double sshift) {
+                                               const float* __restrict__ w, const float* __restrict__ bfirst,
+                                               float* __restrict__ out, int H, int W, double srange, double sshift,
+                                               int clamp01, float slope) {
     __shared__ float ws[C * 9];
+    __shared__ float bs[C];
     for (int i = threadIdx.x; i < C * 9; i += 256) ws[i] = w[i];
+    if (threadIdx.x < C) bs[threadIdx.x] = bfirst[threadIdx.x];
     __syncthreads();
     const int b = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -603,8 +608,13 @@ __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T*
         const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
         float q = 0.f;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            T u = (zi[yy * W + xx] - lo) / (hi - lo);
-            u = u * (T)srange + (T)sshift;
+            T u = zi[yy * W + xx];
+            if (clamp01) {
+                u = u < (T)0 ? (T)0 : (u > (T)1 ? (T)1 : u);
+            } else {
+                u = (u - lo) / (hi - lo);
+                u = u * (T)srange + (T)sshift;
+            }
             q = (float)u;
         }
         v[t] = q;
@@ -614,7 +624,8 @@ __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T*
         float a = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) a = fmaf(ws[c * 9 + t], v[t], a);
-        out[((size_t)b * C + c) * H * W + p] = a > 0.f ? a : 0.f;
+        a += bs[c];                                             // 0 for the DnCNN family (bias-free first layer)
+        out[((size_t)b * C + c) * H * W + p] = a > 0.f ? a : slope * a + 0.f;
     }
 }
 
@@ -630,7 +641,7 @@ __global__ __launch_bounds__(256) void k_last(const float* __restrict__ act, con
                                               const T* __restrict__ zin, const T* __restrict__ mm,
                                               T* zout, float* __restrict__ r_out,
                                               const T* __restrict__ xrec, double* __restrict__ sse_part, int H, int W,
-                                              double srange, double sshift) {
+                                              double srange, double sshift, int skip01, float blast) {
     __shared__ float ws[C * 9];
     __shared__ __attribute__((aligned(16))) float tile[LT_CK * LT_PR * LT_PC];
     __shared__ double red[4];
@@ -678,8 +689,20 @@ __global__ __launch_bounds__(256) void k_last(const float* __restrict__ act, con
             const int x = tx0 + px + j;
             if (x >= W) continue;
             const size_t p = (size_t)b * H * W + (size_t)y * W + x;
+            r[j] += blast;                                      // 0 for the DnCNN family (bias-free last layer)
             if (r_out != nullptr) r_out[p] = r[j];
-            if (zout != nullptr) {
+            if (zout != nullptr && skip01) {
+                // MMO form: out = clip(clamp(x,0,1) + net(clamp(x,0,1)), 0, 1), fp32 like the reference's tensors
+                // (MMODenoise.py:30-32,98, then the float64 np.clip of :128 which is a no-op after the clamp)
+                const float xin = (float)zin[p];
+                float v = (xin < 0.f ? 0.f : (xin > 1.f ? 1.f : xin)) + r[j];
+                v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+                zout[p] = (T)v;
+                if (xrec != nullptr) {
+                    const double d = (double)xrec[p] - (double)(T)v;
+                    err += d * d;
+                }
+            } else if (zout != nullptr) {
                 const T lo = mm[2 * b], hi = mm[2 * b + 1];
                 T v = (zin[p] - lo) / (hi - lo);
                 v = v * (T)srange + (T)sshift;                  // xtilde, kept in T (f64 in the reference wrapper)
@@ -717,6 +740,8 @@ using namespace pnp;
 struct pnp_dncnn_plan {
     int n_mid, H, W, batch, num_cu;
     float *w_first, *w_last, *wpack, *upack, *bias;   // device (upack: Winograd F(2,3)-transformed weights)
+    float* b_first;                              // [64] device, zeros unless pnp_dncnn_set_affine
+    float b_last, slope;                         // last-layer bias, LeakyReLU slope (0 = ReLU)
     int use_wino;
     float *act0, *act1, *zeros;                  // [B][64][H][W] x2; a zero word for halo padding
     double* mm;                                  // [B][2] (as double or float depending on call)
@@ -782,6 +807,8 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e == hipSuccess) e = hipMemcpy(p->w_first, w_first, C * 9 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->w_last, C * 9 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->w_last, w_last, C * 9 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->b_first, C * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(p->b_first, 0, C * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&p->act0, act_bytes);
     if (e == hipSuccess) e = hipMalloc(&p->act1, act_bytes);
     if (e == hipSuccess) e = hipMalloc(&p->zeros, 256);
@@ -791,7 +818,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e != hipSuccess) {
         set_error(std::string("pnp_dncnn_plan_create: ") + hipGetErrorString(e));
         for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
-                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part})
+                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first})
             if (q) (void)hipFree(q);
         delete p;
         return PNP_ERR_HIP;
@@ -803,7 +830,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
 extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
     if (!p) return PNP_OK;
     for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
-                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part})
+                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first})
         (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -813,7 +840,7 @@ extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
 namespace {
 template <typename T>
 int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net, T* z_out, float* r_out,
-              const T* xrec, double* sse_out, hipStream_t s) {
+              const T* xrec, double* sse_out, hipStream_t s, bool mmo = false) {
     const int H = p->H, W = p->W, B = p->batch, HW = H * W;
     T* mm = normalise ? (T*)p->mm : nullptr;             // raw network (no wrapper scaling): lo = 0, hi = 1
     double srange = 1.0, sshift = 0.0;
@@ -824,7 +851,7 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
         sshift = (1.0 - srange) / 2.0;
     }
     dim3 pg(HW / 256, B);
-    k_first<T><<<pg, 256, 0, s>>>(z_in, mm, p->w_first, p->act0, H, W, srange, sshift);
+    k_first<T><<<pg, 256, 0, s>>>(z_in, mm, p->w_first, p->b_first, p->act0, H, W, srange, sshift, mmo ? 1 : 0, p->slope);
     PNP_CHECK_LAUNCH();
     const int ntiles = B * (H / TR) * (W / TC);
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
@@ -832,7 +859,14 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     const bool prof = p->profile && p->ev_used + 2 <= p->ev.size();
     if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
     for (int l = 0; l < p->n_mid; ++l) {
-        if (p->use_wino == 2) {
+        if (p->slope != 0.f) {                             // LeakyReLU builds exist for the two production kernels
+            if (p->use_wino)
+                k_mid_wino<true, false, true><<<grid, 256, 0, s>>>(src, dst, p->upack + (size_t)l * 4 * WINO_U * 64,
+                                                                  p->bias + (size_t)l * C, p->zeros, H, W, ntiles, nullptr, p->slope);
+            else
+                k_mid<true, false, 0, true><<<grid, 256, 0, s>>>(src, dst, p->wpack + (size_t)l * 4 * 2 * KSTEPS_HALF * 64,
+                                                                p->bias + (size_t)l * C, p->zeros, H, W, ntiles, nullptr, p->slope);
+        } else if (p->use_wino == 2) {
             const int nt2 = B * (H / W2_TR) * (W / TC);
             const int g2 = nt2 < 2 * p->num_cu ? nt2 : 2 * p->num_cu;
             k_mid_wino2<true><<<g2, 256, 0, s>>>(src, dst, p->upack + (size_t)l * 4 * WINO_U * 64, p->bias + (size_t)l * C,
@@ -849,7 +883,7 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     if (prof) { PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used + 1], s)); p->ev_used += 2; }
     dim3 lg((W + LT_C - 1) / LT_C, (H + LT_R - 1) / LT_R, B);
     k_last<T><<<lg, 256, 0, s>>>(src, p->w_last, z_in, mm, z_out, r_out, xrec, sse_out ? p->sse_part : nullptr, H, W,
-                                 srange, sshift);
+                                 srange, sshift, mmo ? 1 : 0, p->b_last);
     PNP_CHECK_LAUNCH();
     if (sse_out) {
         k_sum_parts<<<B, 64, 0, s>>>(p->sse_part, (int)(lg.x * lg.y), sse_out);
@@ -858,6 +892,16 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     return PNP_OK;
 }
 }  // namespace
+
+extern "C" int pnp_dncnn_set_affine(pnp_dncnn_plan* p, const float* b_first, float b_last, float negative_slope) {
+    PNP_CHECK_ARG(p != nullptr, "null plan");
+    PNP_CHECK_ARG(negative_slope >= 0.f && negative_slope < 1.f, "negative_slope must be in [0, 1)");
+    if (b_first) PNP_CHECK_HIP(hipMemcpy(p->b_first, b_first, C * sizeof(float), hipMemcpyHostToDevice));
+    else PNP_CHECK_HIP(hipMemset(p->b_first, 0, C * sizeof(float)));
+    p->b_last = b_last;
+    p->slope = negative_slope;
+    return PNP_OK;
+}
 
 extern "C" int pnp_dncnn_set_winograd(pnp_dncnn_plan* p, int enable) {
     PNP_CHECK_ARG(p != nullptr, "null plan");
@@ -933,6 +977,19 @@ extern "C" int pnp_dncnn_debug_clock(pnp_dncnn_plan* p, int reps, double* cycles
 extern "C" int pnp_dncnn_forward(pnp_dncnn_plan* p, const float* x, float* r, void* stream) {
     PNP_CHECK_ARG(p && x && r, "null argument");
     return run_dncnn<float>(p, x, false, 0.0, nullptr, r, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pnp_mmo_denoise(pnp_dncnn_plan* p, const void* z_in, void* z_out, int dtype, const void* xrec,
+                               double* sse_out, void* stream) {
+    PNP_CHECK_ARG(p && z_in && z_out, "null argument");
+    PNP_CHECK_ARG(!(sse_out && !xrec), "sse_out needs xrec");
+    if (dtype == PNP_F32)
+        return run_dncnn<float>(p, (const float*)z_in, false, 0.0, (float*)z_out, nullptr, (const float*)xrec, sse_out,
+                                (hipStream_t)stream, true);
+    if (dtype == PNP_F64)
+        return run_dncnn<double>(p, (const double*)z_in, false, 0.0, (double*)z_out, nullptr, (const double*)xrec, sse_out,
+                                 (hipStream_t)stream, true);
+    PNP_CHECK_ARG(false, "bad dtype");
 }
 
 extern "C" int pnp_dncnn_denoise(pnp_dncnn_plan* p, const void* z_in, void* z_out, int dtype, double sigma_net,

@@ -199,15 +199,65 @@ class NLMDenoiser(Denoise):
         return out.reshape(H, W).double().cpu().numpy()
 
 
-class MMODenoiser(Denoise):
-    """reference denoisers/MMODenoise.py:105-128.  Its checkpoints are whole pickled modules (loadable only
-    with weights_only=False, i.e. arbitrary code execution) and it is not on any BASELINE config: out of scope
-    (SURVEY section 2, 8f n3).  The class exists so that `from denoisers.MMODenoise import MMODenoiser`
-    (reference pnp_csmri.py:7) keeps importing."""
+def mmo_weights_from_state_dict(sd, negative_slope=0.01):
+    """`simple_CNN` state dict (reference MMODenoise.py:80-82: in_conv, conv_list.{i}, out_conv, each with a bias;
+    an optional DataParallel 'module.' prefix is dropped) -> the weight dict `ops.DncnnPlan` takes.  The reference
+    feeds the network the transposed image (MMODenoise.py:124), which is the same as transposing every 3x3 kernel."""
+    sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+    n_mid = len([k for k in sd if k.startswith('conv_list.') and k.endswith('.weight')])
+    names = ['in_conv'] + [f'conv_list.{i}' for i in range(n_mid)] + ['out_conv']
+    out = {'n_layers': np.int64(len(names)), 'negative_slope': float(negative_slope), 'transpose_taps': True}
+    for i, n in enumerate(names):
+        out[f'conv{i}.weight'] = np.asarray(sd[n + '.weight'].detach().cpu().numpy() if hasattr(sd[n + '.weight'], 'detach') else sd[n + '.weight'])
+        out[f'conv{i}.bias'] = np.asarray(sd[n + '.bias'].detach().cpu().numpy() if hasattr(sd[n + '.bias'], 'detach') else sd[n + '.bias'])
+    return out
 
-    def __init__(self, *args, **kwargs):
+
+class MMODenoiser(Denoise):
+    """reference denoisers/MMODenoise.py:105-128: the 20-layer bias/LeakyReLU/skip network `simple_CNN` (:73-101) on
+    the MFMA conv stack.  `model` may be the reference's torch module (plain or DataParallel) or a
+    state dict; `weights=` takes a ready weight dict.  With neither, the reference's checkpoint path is tried with
+    `weights_only=True`: the files the reference ships are whole pickled modules, which that loader refuses by design
+    -- re-save `model.module.state_dict()` once and pass the file as `path=`.  Single-channel images only.
+    Like the reference: `t` advances per call, `sigma_est` is ignored, the result is float32 in [0, 1]."""
+
+    def __init__(self, model=None, channels=3, path=None, cuda=True, sigma=0.01, root_path='.', *, weights=None):
         super().__init__()
-        self._args = (args, kwargs)
+        self.sigma = sigma
+        if channels != 1:
+            raise NotImplementedError('MMODenoiser on the MI355X path handles single-channel (2-D) images: channels=1')
+        if weights is None:
+            if model is None:
+                pth = path if path is not None else (root_path + 'checkpoints/pretrained/DnCNN_nobn_nch_' + str(channels)
+                                                     + '_nlev_' + str(sigma) + '.pth')
+                model = torch.load(pth, map_location='cpu', weights_only=True)   # FileNotFoundError like the reference
+            if hasattr(model, 'module'):
+                model = model.module
+            sd = model.state_dict() if hasattr(model, 'state_dict') else model
+            weights = mmo_weights_from_state_dict(sd)
+        else:
+            weights = dict(weights)
+            weights.setdefault('transpose_taps', True)
+            weights.setdefault('negative_slope', 0.01)
+        self.model = weights
+        self._plans = {}
+
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key not in self._plans:
+            self._plans[key] = ops.DncnnPlan(self.model, H, W, B)
+        return self._plans[key]
+
+    def denoise_device(self, z, sigma_est=None, xrec=None, out=None, sse=None):
+        self.t += 1
+        B, H, W = z.shape
+        out, sse = self._plan(B, H, W).mmo_denoise(z, xrec=xrec, out=out, sse=sse)
+        return out, sse, None
 
     def denoise(self, noisy, sigma_est=0):
-        raise NotImplementedError('MMODenoiser is not part of the MI355X hot path (pickled-module checkpoints)')
+        z = _as_dev(noisy)
+        H, W = z.shape[-2:]
+        out, _, _ = self.denoise_device(z.reshape(1, H, W))
+        if isinstance(noisy, torch.Tensor):
+            return out.reshape(noisy.shape)
+        return out.reshape(H, W).float().cpu().numpy()

@@ -87,7 +87,9 @@ class DncnnPlan:
 
     `weights`: dict of NumPy arrays in the reference's layer order -- conv{i}.weight (i = 0..n-1) and
     bn{i}.{weight,bias,mean,var} for the middle layers -- exactly what tests/golden/dncnn_noise15.npz
-    holds or what `load_dncnn_state_dict` extracts from a reference .pth.  BatchNorm (eval) is folded here."""
+    holds or what `load_dncnn_state_dict` extracts from a reference .pth.  BatchNorm (eval) is folded here.
+    Optional `conv{i}.bias` arrays (any layer), `negative_slope` (LeakyReLU instead of ReLU) and
+    `transpose_taps` (every 3x3 kernel transposed) cover the MMO `simple_CNN` (denoisers/MMODenoise.py:73-101)."""
 
     def __init__(self, weights, H, W, batch, winograd=None):
         """winograd: True = F(2,3) conv kernel (default; fp32, 2/3 of the matrix-core work),
@@ -96,22 +98,35 @@ class DncnnPlan:
         require_gpu()
         n = int(weights['n_layers'])
         self.H, self.W, self.B, self.n_mid = H, W, batch, n - 2
-        w_first = np.ascontiguousarray(weights['conv0.weight'], dtype=np.float32).reshape(64, 9)
-        w_last = np.ascontiguousarray(weights[f'conv{n - 1}.weight'], dtype=np.float32).reshape(64, 9)
+        tr = bool(weights.get('transpose_taps', False))
+
+        def taps(name, shape):
+            w = np.asarray(weights[name], dtype=np.float64).reshape(shape + (3, 3))
+            return (w.swapaxes(-1, -2) if tr else w).reshape(shape + (9,))
+
+        w_first = np.ascontiguousarray(taps('conv0.weight', (64,)), dtype=np.float32)
+        w_last = np.ascontiguousarray(taps(f'conv{n - 1}.weight', (64,)), dtype=np.float32)
         w_mid = np.empty((n - 2, 64, 64, 9), dtype=np.float32)
         b_mid = np.zeros((n - 2, 64), dtype=np.float32)
         for i in range(1, n - 1):
-            w = np.asarray(weights[f'conv{i}.weight'], dtype=np.float64).reshape(64, 64, 9)
+            w = taps(f'conv{i}.weight', (64, 64))
+            b = np.asarray(weights[f'conv{i}.bias'], np.float64) if f'conv{i}.bias' in weights else np.zeros(64)
             if f'bn{i}.weight' in weights:
                 s = np.asarray(weights[f'bn{i}.weight'], np.float64) / np.sqrt(np.asarray(weights[f'bn{i}.var'], np.float64) + 1e-5)
                 w = w * s[:, None, None]
-                b_mid[i - 1] = (np.asarray(weights[f'bn{i}.bias'], np.float64) - np.asarray(weights[f'bn{i}.mean'], np.float64) * s)
+                b = np.asarray(weights[f'bn{i}.bias'], np.float64) + (b - np.asarray(weights[f'bn{i}.mean'], np.float64)) * s
+            b_mid[i - 1] = b
             w_mid[i - 1] = w
         h = ctypes.c_void_p()
         N.call('pnp_dncnn_plan_create', ctypes.byref(h), n - 2, w_first.ctypes.data_as(ctypes.c_void_p),
                w_mid.ctypes.data_as(ctypes.c_void_p), b_mid.ctypes.data_as(ctypes.c_void_p),
                w_last.ctypes.data_as(ctypes.c_void_p), H, W, batch)
         self._h = h
+        slope = float(weights.get('negative_slope', 0.0))
+        if slope != 0.0 or 'conv0.bias' in weights or f'conv{n - 1}.bias' in weights:
+            b_first = np.ascontiguousarray(weights.get('conv0.bias', np.zeros(64)), dtype=np.float32)
+            b_last = float(np.asarray(weights.get(f'conv{n - 1}.bias', 0.0)).reshape(-1)[0])
+            N.call('pnp_dncnn_set_affine', self._h, b_first.ctypes.data_as(ctypes.c_void_p), b_last, slope)
         if winograd is not None:
             N.call('pnp_dncnn_set_winograd', self._h, int(winograd))   # 0 direct, 1 Winograd, 2 Winograd two-WG/CU
 
@@ -145,6 +160,16 @@ class DncnnPlan:
         if xrec is not None and sse is None:
             sse = torch.empty(self.B, dtype=torch.float64, device=z.device)
         N.call('pnp_dncnn_denoise', self._h, _p(z), _p(out), _DT[z.dtype], float(sigma_net), _p(xrec), _p(sse), _stream())
+        return out, sse
+
+
+    def mmo_denoise(self, z, xrec=None, out=None, sse=None):
+        """pnp_mmo_denoise: clip(xc + net(xc), 0, 1), xc = clip(z, 0, 1) (reference MMODenoise.py:18-40,88-101)."""
+        assert tuple(z.shape) == (self.B, self.H, self.W)
+        out = out if out is not None else torch.empty_like(z)
+        if xrec is not None and sse is None:
+            sse = torch.empty(self.B, dtype=torch.float64, device=z.device)
+        N.call('pnp_mmo_denoise', self._h, _p(z), _p(out), _DT[z.dtype], _p(xrec), _p(sse), _stream())
         return out, sse
 
 

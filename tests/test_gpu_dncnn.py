@@ -99,3 +99,59 @@ def test_simplecnn_family(name):
     for wino in (1, 0, 2):
         r = ops.DncnnPlan(w, 64, 64, 1, winograd=wino).forward(dev(g['net64_in'][None])).cpu().numpy()[0]
         assert np.abs(r - g[f'{name}_out']).max() <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('winograd', [True, False])
+def test_mmo_denoiser_vs_reference(winograd):
+    """SURVEY 8(f) n3: MMODenoiser (20-layer bias / LeakyReLU(0.01) / skip net, transposed input, both clamps;
+    reference denoisers/MMODenoise.py:18-40,73-128) through the MFMA conv stack vs the reference's own classes
+    (tests/golden/make_golden_mmo.py), NumPy protocol: float32 result, t advances."""
+    from pnp_svrg_amd.denoisers import MMODenoiser, mmo_weights_from_state_dict
+    import os
+    g = golden('mmo_seeded.npz')
+    names = ['in_conv'] + [f'conv_list.{i}' for i in range(18)] + ['out_conv']
+    sd = {}
+    for i, n in enumerate(names):
+        sd['module.' + n + '.weight'] = torch.from_numpy(g[f'conv{i}.weight'])
+        sd['module.' + n + '.bias'] = torch.from_numpy(g[f'conv{i}.bias'])
+    old = os.environ.get('PNP_DNCNN_WINOGRAD')
+    os.environ['PNP_DNCNN_WINOGRAD'] = '1' if winograd else '0'
+    try:
+        den = MMODenoiser(model=sd, channels=1)
+        for name in ('sq', 'rect'):
+            y = den.denoise(g[f'{name}_in'])
+            assert y.dtype == np.float32 and y.shape == g[f'{name}_out'].shape
+            assert np.abs(y - g[f'{name}_out']).max() <= 2e-5, (name, np.abs(y - g[f'{name}_out']).max())
+            assert y.min() == 0.0 and y.max() == 1.0
+    finally:
+        if old is None:
+            os.environ.pop('PNP_DNCNN_WINOGRAD')
+        else:
+            os.environ['PNP_DNCNN_WINOGRAD'] = old
+    assert den.t == 2
+    w = mmo_weights_from_state_dict(sd)
+    assert int(w['n_layers']) == 20 and w['transpose_taps'] is True
+    with pytest.raises(NotImplementedError):
+        MMODenoiser(model=sd, channels=3)
+
+
+@pytest.mark.gpu
+def test_mmo_device_batch_and_sse():
+    """denoise_device on a batch (f64 storage): every image equals the single-image result; the fused squared error
+    equals the one recomputed from the output."""
+    from pnp_svrg_amd.denoisers import MMODenoiser
+    g = golden('mmo_seeded.npz')
+    w = {k: g[k] for k in g.files if k.startswith('conv') or k in ('n_layers', 'negative_slope')}
+    den = MMODenoiser(weights=w, channels=1)
+    x = g['rect_in']
+    z = dev(np.stack([x, x[::-1].copy(), 0.5 * x]), torch.float64)
+    xrec = dev(np.stack([g['rect_out']] * 3).astype(np.float64), torch.float64)
+    out, sse, _ = den.denoise_device(z, xrec=xrec)
+    o = out.cpu().numpy()
+    assert np.abs(o[0] - g['rect_out']).max() <= 2e-5
+    for b in range(3):
+        single = den.denoise(z[b].cpu().numpy())
+        assert np.abs(single - o[b]).max() <= 1e-6
+    ref = ((xrec.cpu().numpy() - o) ** 2).sum(axis=(1, 2))
+    assert np.allclose(sse.cpu().numpy(), ref, rtol=1e-10, atol=1e-12)

@@ -3,7 +3,7 @@
 import os
 import numpy as np
 import pytest
-from conftest import GOLDEN
+from conftest import GOLDEN, golden
 
 import oracle
 from oracle import denoise as od, problems as op, loops as ol
@@ -235,3 +235,16 @@ def test_dncnn_oracle():
     den = golden('denoise.npz')
     out = od.DnCNNDenoiser(w, 15).denoise(noisy=den['s64_z0'], sigma_est=0.1)
     np.testing.assert_allclose(out, io['den64_s15'], rtol=0, atol=5e-6)
+
+
+def test_mmo_oracle():
+    """oracle.MMODenoiser (transpose, clamp, bias/LeakyReLU/skip net) == the reference's MMODenoiser.denoise run on its
+    own simple_CNN class (tests/golden/make_golden_mmo.py), square and rectangular images."""
+    g = golden('mmo_seeded.npz')
+    w = {k: g[k] for k in g.files if k.startswith('conv') or k in ('n_layers', 'negative_slope')}
+    den = od.MMODenoiser(w)
+    for name in ('sq', 'rect'):
+        y = den.denoise(g[f'{name}_in'])
+        assert y.dtype == np.float32 and y.shape == g[f'{name}_out'].shape
+        assert np.abs(y - g[f'{name}_out']).max() <= 2e-6
+    assert den.t == 2

@@ -182,3 +182,25 @@ def test_reference_driver_imports():
         assert n in ns, n
     # constructing the classic denoisers needs no GPU (pnp_csmri.py:18-20 does it at import time)
     ns['BM3DDenoiser'](); ns['NLMDenoiser'](); ns['TVDenoiser']()
+
+
+def test_display_results_contract(tmp_path, capsys):
+    """Utilities.display_results consumes the loops' result dict; the printed line reproduces the
+    reference's mis-indexed format string (Utilities.py:51-53) unless asked otherwise, the CSV is indexed correctly."""
+    import matplotlib
+    matplotlib.use('Agg')
+    import types
+    from Utilities import display_results, metrics_line
+    out = {'z': np.linspace(0, 1, 64), 'time_per_iter': [0.1] * 5, 'psnr_per_iter': [10.0, 11.0, 12.5, 13.0, 13.46],
+           'gradient_time': 0.27, 'denoise_time': 9.75, 'algo_name': 'pnp_svrg'}
+    prob = types.SimpleNamespace(H=8, W=8, color_map='gray', prob_dir=str(tmp_path) + '/')
+    ax = display_results(prob, out, save_results=True)
+    line = capsys.readouterr().out.strip().split('\n')[-1]
+    assert line == 'Output PSNR: 13.5\tChange in PSNR: 0.27\tGradient Time: 9.75\tDenoising Time: 9.75'
+    assert metrics_line(out, reference_labels=False) == 'Output PSNR: 13.5\tChange in PSNR: 3.46\tGradient Time: 0.27\tDenoising Time: 9.75'
+    d = tmp_path / 'pnp_svrg'
+    assert sorted(p.name for p in d.iterdir()) == ['output.csv', 'output.eps', 'psnr_over_time.eps']
+    rows = (d / 'output.csv').read_text().strip().split('\n')
+    assert rows[0] == 'Output PSNR,Change in PSNR,Gradient Time,Denoising Time'
+    assert [float(v) for v in rows[1].split(',')] == [13.5, 3.46, 0.27, 9.75]
+    assert ax.get_xlabel() == 'time (s)' and len(ax.lines) == 2

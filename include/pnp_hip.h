@@ -93,6 +93,10 @@ int pnp_deblur_forward(pnp_deblur_plan* plan, const void* x, void* out, void* st
 size_t pnp_pr_workspace_elems(int M, int N);
 int pnp_pr_grad(const void* A, const void* w, const void* y, const int32_t* rows, int nsel, int M, int N,
                 int dtype, double scale, void* workspace, void* out, void* stream);
+/* One power-iteration step of PhaseRetrieval.spec_init (problems/PR.py:50-63): out = scale * A^T (y o (A v)), i.e.
+ * D v for D = A^T diag(y) A / M (scale = 1/M) without forming the N x N matrix.  v, out [N]; same workspace.      */
+int pnp_pr_spectral_apply(const void* A, const void* v, const void* y, int M, int N, int dtype, double scale,
+                          void* workspace, void* out, void* stream);
 
 /* ------------------------------------------------------------------ prox / noise estimate
  * estimate_sigma(z0, multichannel=True, average_sigmas=True) (algorithms/pnp_svrg.py:71):

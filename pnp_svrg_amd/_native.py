@@ -34,6 +34,7 @@ SIGNATURES = {
     'pnp_deblur_forward': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_pr_workspace_elems': (_sz, [_i, _i]),
     'pnp_pr_grad': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
+    'pnp_pr_spectral_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
     'pnp_sigma_est': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'pnp_prox_tv': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _d, _d, _vp, _vp, _vp, _vp]),
     'pnp_nlm2d': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _d, _d, _vp, _d, _vp, _vp, _vp, _vp]),

@@ -9,7 +9,9 @@
 
 namespace pnp {
 
-template <typename T>
+// SPECTRAL: the row weight is y[m] (u = y o (A w)): one application of A^T diag(y) A, the matrix whose leading
+// eigenvector is the spectral initialisation (PR.py:50-63) -- never formed, the power iteration streams A twice.
+template <typename T, bool SPECTRAL = false>
 __global__ __launch_bounds__(256) void k_pr_rows(const T* __restrict__ A, const T* __restrict__ w, const T* __restrict__ y,
                                                  const int32_t* __restrict__ rows, int nsel, int N, T* __restrict__ u) {
     const int wv = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -21,7 +23,7 @@ __global__ __launch_bounds__(256) void k_pr_rows(const T* __restrict__ A, const 
     acc = wave_sum(acc);
     if (lane == 0) {
         const T mag = acc < 0 ? -acc : acc;
-        u[wv] = ((mag - y[m]) / mag) * acc;
+        u[wv] = SPECTRAL ? y[m] * acc : ((mag - y[m]) / mag) * acc;
     }
 }
 
@@ -51,11 +53,12 @@ __global__ void k_pr_reduce(const T* __restrict__ part, int nchunks, int N, T sc
 
 template <typename T>
 int run_pr(const T* A, const T* w, const T* y, const int32_t* rows, int nsel, int M, int N, double scale, T* ws, T* out,
-           hipStream_t s) {
+           hipStream_t s, bool spectral = false) {
     const int nchunks = 64;
     T* u = ws;                       // [nsel]
     T* part = ws + M;                // [nchunks][N]
-    k_pr_rows<T><<<(nsel * 64 + 255) / 256, 256, 0, s>>>(A, w, y, rows, nsel, N, u);
+    if (spectral) k_pr_rows<T, true><<<(nsel * 64 + 255) / 256, 256, 0, s>>>(A, w, y, rows, nsel, N, u);
+    else k_pr_rows<T><<<(nsel * 64 + 255) / 256, 256, 0, s>>>(A, w, y, rows, nsel, N, u);
     PNP_CHECK_LAUNCH();
     const int rpc = (nsel + nchunks - 1) / nchunks;
     k_pr_cols<T><<<dim3((N + 255) / 256, nchunks), 256, 0, s>>>(A, u, rows, nsel, N, rpc, part);
@@ -83,5 +86,19 @@ extern "C" int pnp_pr_grad(const void* A, const void* w, const void* y, const in
         return run_pr<float>((const float*)A, (const float*)w, (const float*)y, rows, nsel, M, N, scale, (float*)workspace, (float*)out, s);
     if (dtype == PNP_F64)
         return run_pr<double>((const double*)A, (const double*)w, (const double*)y, rows, nsel, M, N, scale, (double*)workspace, (double*)out, s);
+    PNP_CHECK_ARG(false, "bad dtype");
+}
+
+// out = scale * A^T ( y o (A v) )  -- one power-iteration step of the spectral initialisation (PR.py:53,59 without
+// the N x N matrix D = A^T diag(y) A / M).  Same workspace as pnp_pr_grad.
+extern "C" int pnp_pr_spectral_apply(const void* A, const void* v, const void* y, int M, int N, int dtype, double scale,
+                                     void* workspace, void* out, void* stream) {
+    PNP_CHECK_ARG(A && v && y && workspace && out, "null argument");
+    PNP_CHECK_ARG(M >= 1 && N >= 1, "bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PNP_F32)
+        return run_pr<float>((const float*)A, (const float*)v, (const float*)y, nullptr, M, M, N, scale, (float*)workspace, (float*)out, s, true);
+    if (dtype == PNP_F64)
+        return run_pr<double>((const double*)A, (const double*)v, (const double*)y, nullptr, M, M, N, scale, (double*)workspace, (double*)out, s, true);
     PNP_CHECK_ARG(false, "bad dtype");
 }

@@ -306,6 +306,17 @@ def pr_grad(A, w, y, rows=None, scale=1.0, workspace=None, out=None):
     return out
 
 
+def pr_spectral_apply(A, v, y, scale=1.0, workspace=None, out=None):
+    """scale * A^T (y o (A v)): one power-iteration step of the PR spectral initialisation; A [M,N]."""
+    require_gpu()
+    M, Nn = A.shape
+    if workspace is None:
+        workspace = torch.empty(N.lib().pnp_pr_workspace_elems(M, Nn), dtype=A.dtype, device=A.device)
+    out = out if out is not None else torch.empty(Nn, dtype=A.dtype, device=A.device)
+    N.call('pnp_pr_spectral_apply', _p(A), _p(v), _p(y), M, Nn, _DT[A.dtype], float(scale), _p(workspace), _p(out), _stream())
+    return out
+
+
 def counter_add(counter, inc=1):
     """counter: int32 device tensor with one element (device-resident step counter)."""
     require_gpu()

@@ -108,3 +108,58 @@ def write_csv(path, results, problem='csmri', denoiser='', algorithm='pnp_svrg',
         w.writerow(['Problem', 'Denoiser', 'Algorithm', 'Alpha', 'SNR', 'Loss', 'PARAMETERS'])
         for r in results:
             w.writerow([problem, denoiser, algorithm, r['item']['alpha'], r['item']['snr'], r['loss'], params])
+
+
+# ---------------------------------------------------------------------------------------------- hyper-parameter search
+def grid_points(grid):
+    """Deterministic trial list from {'eta': [...], 'mini_batch_size': [...], 'T2': [...]}: the cartesian product in
+    the key order given (the reference draws trials with hyperopt TPE, script_diff_sampratio_set12.py:116-123; a fixed
+    grid is the reproducible replacement -- every item sees the same trials, so trials batch over items)."""
+    import itertools
+    keys = list(grid)
+    return [dict(zip(keys, vals)) for vals in itertools.product(*(grid[k] for k in keys))]
+
+
+def best_over_trials(per_trial):
+    """per_trial: list of (params, [result dict per item]) -> one row per item with the minimum loss (ties: first trial,
+    like hyperopt's best_trial on equal losses) and the parameters that achieved it.  NaN losses never win."""
+    best = {}
+    for params, results in per_trial:
+        for r in results:
+            cur = best.get(r['id'])
+            loss = r['loss']
+            if cur is None or (not np.isnan(loss) and (np.isnan(cur['loss']) or loss < cur['loss'])):
+                best[r['id']] = {'id': r['id'], 'item': r['item'], 'loss': loss, 'params': dict(params),
+                                 'psnr_init': r.get('psnr_init'), 'psnr_final': r.get('psnr_final')}
+    return [best[k] for k in sorted(best)]
+
+
+def grid_search(items, make_runner, grid, group=None):
+    """The sweep the reference scripts run (process_img, script_diff_sampratio_set12.py:103-131): for every work item
+    search the hyper-parameters and keep the best trial.  `make_runner(**params)` returns a runner as `run_sweep`
+    takes; each rank runs every trial on ITS shard of the items (one batched engine per trial), the reduction over
+    trials is local and the single gather at the end carries one small row per item."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    mine = shard(items, rank, world)
+    per_trial = []
+    for params in grid_points(grid):
+        res = make_runner(**params)(mine) if mine else []
+        per_trial.append((params, [{k: v for k, v in r.items() if k != 'z'} for r in res]))
+    return gather_results(best_over_trials(per_trial), 0, group)
+
+
+def write_tuning_csv(path, rows, problem='csmri', denoiser='', algorithm='pnp_svrg'):
+    """The reference's result file, row for row (script_diff_sampratio_set12.py:131-136,153-160): a 'Results:' line,
+    then Problem,Denoiser,Algorithm,Alpha,SNR,Loss,'PARAMETERS:',key,value,key,value,..."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, 'w', newline='') as f:
+        w = csv.writer(f, delimiter=',')
+        w.writerow(['Results:'])
+        for r in rows:
+            row = [problem, denoiser, algorithm, r['item']['alpha'], r['item']['snr'], r['loss'], 'PARAMETERS:']
+            for k, v in r['params'].items():
+                row += [k, v]
+            w.writerow(row)

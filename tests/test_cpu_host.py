@@ -204,3 +204,37 @@ def test_display_results_contract(tmp_path, capsys):
     assert rows[0] == 'Output PSNR,Change in PSNR,Gradient Time,Denoising Time'
     assert [float(v) for v in rows[1].split(',')] == [13.5, 3.46, 0.27, 9.75]
     assert ax.get_xlabel() == 'time (s)' and len(ax.lines) == 2
+
+
+def test_grid_search_reduction_and_csv(tmp_path):
+    """deterministic grid replacement for the reference's per-item hyperopt search -- trial order,
+    best-trial reduction (first wins ties, NaN never wins) and the reference's CSV rows."""
+    from pnp_svrg_amd import sweep
+    items = sweep.make_items(2, [0.2, 0.4], [20.0])
+    grid = {'eta': [1.0, 2.0, 4.0], 'T2': [5, 10]}
+    pts = sweep.grid_points(grid)
+    assert pts[0] == {'eta': 1.0, 'T2': 5} and pts[1] == {'eta': 1.0, 'T2': 10} and len(pts) == 6
+    calls = []
+
+    def make_runner(eta, T2):
+        def run(mine):
+            calls.append((eta, T2, len(mine)))
+            out = []
+            for it in mine:
+                loss = abs(eta - 2.0) + 0.01 * T2 - it['alpha']          # minimum at eta=2, T2=5 for every item
+                if it['id'] == 3 and eta == 2.0:
+                    loss = float('nan')                                  # a diverged trial
+                out.append({'id': it['id'], 'item': it, 'loss': loss, 'z': np.zeros(4)})
+            return out
+        return run
+    rows = sweep.grid_search(items, make_runner, grid)
+    assert [c[:2] for c in calls] == [(p['eta'], p['T2']) for p in pts] and all(c[2] == 4 for c in calls)
+    assert [r['id'] for r in rows] == [0, 1, 2, 3]
+    assert all(r['params'] == {'eta': 2.0, 'T2': 5} for r in rows[:3])
+    assert rows[3]['params'] == {'eta': 1.0, 'T2': 5} and 'z' not in rows[0]      # first of the tied eta=1/eta=4... lowest loss, first seen
+    p = tmp_path / 'hyperparam-tuning' / 'out.csv'
+    sweep.write_tuning_csv(str(p), rows, denoiser='TV')
+    lines = p.read_text().strip().split('\n')
+    assert lines[0] == 'Results:' and len(lines) == 5
+    assert lines[1].split(',')[:5] == ['csmri', 'TV', 'pnp_svrg', '0.2', '20.0']
+    assert lines[1].split(',')[6:] == ['PARAMETERS:', 'eta', '2.0', 'T2', '5']

@@ -139,3 +139,32 @@ def test_deblur_128_vs_oracle(dtype, scale):
     rel = 1e-10 if dtype == torch.float64 else 3e-4
     for got, ref in ((p.grad_full(po.Xinit), po.grad_full(po.Xinit)), (p.grad_stoch(po.Xinit, mb), po.grad_stoch(po.Xinit, mb))):
         assert np.abs(got - ref).max() <= rel * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+def test_pr_spectral_apply(dtype, tol):
+    """pnp_pr_spectral_apply == D v for D = A^T diag(y) A / M (reference PR.py:53,59), ragged M and N."""
+    from pnp_svrg_amd import ops
+    rng = np.random.default_rng(3)
+    M, N = 301, 250
+    A, y, v = rng.standard_normal((M, N)), np.abs(rng.standard_normal(M)), rng.standard_normal(N)
+    ref = (A.T @ (A * y[:, None]) / M) @ v
+    dev = lambda a: torch.from_numpy(a).to('cuda', dtype)
+    got = ops.pr_spectral_apply(dev(A), dev(v), dev(y), scale=1.0 / M).double().cpu().numpy()
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+
+
+def test_pr_spectral_init_matches_matrix_power_iteration():
+    """Device power iteration (never forms D) vs the oracle's restatement of PR.py:50-63 (forms D) on a problem that
+    is not the golden one: same Xinit to 1e-9, in both storage dtypes of the problem."""
+    from oracle import problems as op
+    from pnp_svrg_amd.problems import PhaseRetrieval
+    import os
+    img = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'synth64.png')
+    np.random.seed(5)
+    ref = op.PhaseRetrieval(img, H=24, W=24, num_meas=3 * 576, snr=25.)
+    for dt in (torch.float64, torch.float32):
+        np.random.seed(5)
+        p = PhaseRetrieval(img, H=24, W=24, num_meas=3 * 576, snr=25., dtype=dt)
+        np.testing.assert_allclose(p.Xinit, ref.Xinit, rtol=0, atol=1e-9)
+        assert p._A_d.dtype == dt and not hasattr(p, '_A64_d')

@@ -124,6 +124,36 @@ def test_sweep_runner_single_process():
     assert res[2]['psnr_final'] > res[0]['psnr_final']
 
 
+def test_grid_search_on_device(tmp_path):
+    """the reference's per-item hyper-parameter search as a deterministic grid, trials batched over
+    items on the engine: the winner per item is the trial with the best final PSNR, equal to running that trial
+    alone, and the result file has the reference's row layout."""
+    from pnp_svrg_amd import sweep
+    from pnp_svrg_amd.engine import TVProx
+    rng = np.random.default_rng(1)
+    imgs = []
+    for _ in range(2):
+        x = rng.random((64, 64))
+        p = np.pad(x, 2, mode='wrap')
+        imgs.append(sum(p[i:i + 64, j:j + 64] for i in range(5) for j in range(5)) / 25.0)
+    items = sweep.make_items(2, [0.2, 0.5], [20.0])
+
+    def make_runner(eta, T2):
+        return sweep.csmri_svrg_runner(imgs, lambda: TVProx(), eta=eta, T2=T2, mini_batch_size=100, n_inner=12, H=64, W=64)
+    grid = {'eta': [1e1, 5e2, 2e3], 'T2': [4, 6]}
+    rows = sweep.grid_search(items, make_runner, grid)
+    assert [r['id'] for r in rows] == [0, 1, 2, 3]
+    for r in rows:
+        alone = {a['id']: a for a in make_runner(**r['params'])(items)}[r['id']]
+        assert alone['loss'] == r['loss']                                   # deterministic: same trial, same loss
+        for params in sweep.grid_points(grid):
+            other = {a['id']: a for a in make_runner(**params)(items)}[r['id']]
+            assert not (other['loss'] < r['loss'])
+    assert any(r['params']['eta'] != 1e1 for r in rows)                     # the tiny step is not the best everywhere
+    sweep.write_tuning_csv(str(tmp_path / 'o.csv'), rows, denoiser='TV')
+    assert (tmp_path / 'o.csv').read_text().startswith('Results:')
+
+
 def test_bench_two_ranks_rehearsal():
     """The N > 1 path of bench.py (barrier, MAX over ranks, final gather) with 2 ranks sharing GPU 0 over gloo
     (RCCL needs one GPU per rank; the driver runs the real N = 2/4/8 on a full node)."""

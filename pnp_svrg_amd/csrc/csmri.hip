@@ -251,10 +251,14 @@ __device__ __forceinline__ uint32_t mb_hash(uint64_t seed, uint32_t step, uint32
     return (uint32_t)(x >> 32);
 }
 
+// CACHE: the keys are hashed once into dynamic LDS (M0 words) and the five sweeps read them back; otherwise
+// (M0 too large for LDS) every sweep re-hashes.  Same keys either way, so the draw does not depend on it.
+template <bool CACHE>
 __global__ __launch_bounds__(1024) void k_draw_mb(const int32_t* __restrict__ mask_idx, int M0, int mb, uint64_t seed,
                                                   uint32_t step, const uint32_t* __restrict__ step_dev,
                                                   uint8_t* __restrict__ selT, int H, int W) {
     if (step_dev != nullptr) step += *step_dev;                  // device-resident counter (hipGraph replays)
+    extern __shared__ uint32_t keys[];
     __shared__ int hist[256];
     __shared__ int s_bin, s_before, s_ntie;
     __shared__ int tie[64];
@@ -262,6 +266,8 @@ __global__ __launch_bounds__(1024) void k_draw_mb(const int32_t* __restrict__ ma
     const int32_t* idx = mask_idx + (size_t)prob * M0;
     uint8_t* out = selT + (size_t)prob * H * W;
     for (int i = tid; i < H * W / 16; i += 1024) reinterpret_cast<uint4*>(out)[i] = make_uint4(0, 0, 0, 0);
+    if (CACHE)
+        for (int j = tid; j < M0; j += 1024) keys[j] = mb_hash(seed, step, prob, j);   // visible after the first barrier below
 
     uint32_t prefix = 0;
     int k = mb;                                                  // rank (1-based) still to locate inside the prefix bucket
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_draw_mb(const int32_t* __restrict__ ma
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         for (int j = tid; j < M0; j += 1024) {
-            const uint32_t key = mb_hash(seed, step, prob, j);
+            const uint32_t key = CACHE ? keys[j] : mb_hash(seed, step, prob, j);
             if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
         }
         __syncthreads();
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(1024) void k_draw_mb(const int32_t* __restrict__ ma
     if (tid == 0) s_ntie = 0;
     __syncthreads();
     for (int j = tid; j < M0; j += 1024) {
-        const uint32_t key = mb_hash(seed, step, prob, j);
+        const uint32_t key = CACHE ? keys[j] : mb_hash(seed, step, prob, j);
         if (key < prefix) {
             const int i = idx[j];
             out[(size_t)(i % W) * H + i / W] = 1;
@@ -394,7 +400,19 @@ extern "C" int pnp_csmri_draw_minibatch(pnp_csmri_plan* p, const int32_t* mask_i
                                         uint32_t step, const uint32_t* step_dev, uint8_t* selT, void* stream) {
     PNP_CHECK_ARG(p && mask_idx && selT, "null argument");
     PNP_CHECK_ARG(M0 >= 1 && M0 <= p->H * p->W && mb >= 1 && mb <= M0, "need 1 <= mb <= M0 <= H*W");
-    k_draw_mb<<<p->batch, 1024, 0, (hipStream_t)stream>>>(mask_idx, M0, mb, seed, step, step_dev, selT, p->H, p->W);
+    constexpr int kMaxCachedKeys = 36 * 1024;                   // 144 KiB of the CU's 160 KiB LDS
+    if (M0 <= kMaxCachedKeys) {
+        static bool attr_set = false;                           // > 64 KiB of dynamic LDS needs the opt-in, once
+        if (!attr_set) {
+            PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_draw_mb<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              kMaxCachedKeys * (int)sizeof(uint32_t)));
+            attr_set = true;
+        }
+        k_draw_mb<true><<<p->batch, 1024, (size_t)M0 * sizeof(uint32_t), (hipStream_t)stream>>>(mask_idx, M0, mb, seed, step,
+                                                                                                step_dev, selT, p->H, p->W);
+    } else {
+        k_draw_mb<false><<<p->batch, 1024, 0, (hipStream_t)stream>>>(mask_idx, M0, mb, seed, step, step_dev, selT, p->H, p->W);
+    }
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }

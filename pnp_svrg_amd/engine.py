@@ -136,6 +136,7 @@ class SvrgEngine:
         # device-resident step counter (mirrors self.s) and scratch row: a whole outer iteration can then be
         # captured once in a hipGraph and replayed (no host-side step index inside the graph)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._dev_step = 0                                      # the value step_dev currently holds
         self.sse_tmp = torch.zeros(batch.B, dtype=torch.float64, device=dev)
         self.graph = None
 
@@ -143,6 +144,7 @@ class SvrgEngine:
         self.z.copy_(self.b.xinit)
         self.s = 0
         self.step_dev.zero_()
+        self._dev_step = 0
         if hasattr(self.prox, 't'):
             self.prox.t = 0
 
@@ -164,8 +166,7 @@ class SvrgEngine:
         else:
             ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
         self.prox(self.z, b.xrec, self.sse_log[s % self.n_log])
-        ops.counter_add(self.step_dev, 1)
-        self.s += 1
+        self.s += 1                                             # eager steps keep the index on the host (no counter launch)
 
     # ---- hipGraph form: one OUTER iteration (full-gradient refresh + T2 inner iterations) = one graph launch
     def _outer_body(self):
@@ -189,6 +190,7 @@ class SvrgEngine:
         per-call state (TVProx with denoise_strength == 0, DnCNNProx).  State is left untouched."""
         assert self.lr_decay == 1.0 and self.s % self.T2 == 0
         assert getattr(self.prox, 'denoise_strength', 0.0) == 0.0
+        self._set_dev_step(self.s)
         keep = (self.z.clone(), self.w.clone(), self.mu.clone(), self.sse_log.clone(), self.step_dev.clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -205,13 +207,21 @@ class SvrgEngine:
         self.graph = g
         return g
 
+    def _set_dev_step(self, s):
+        """The device-resident counter is brought up to date only when a graph is about to read it."""
+        if self._dev_step != s:
+            self.step_dev.fill_(s)
+            self._dev_step = s
+
     def run_outer(self, n_outer=1):
         """n_outer graph replays = n_outer * T2 inner iterations."""
         if self.graph is None:
             self.capture()
+        self._set_dev_step(self.s)
         for _ in range(n_outer):
             self.graph.replay()
             self.s += self.T2
+        self._dev_step = self.s
 
     def psnr_trace(self):
         """[steps][B] PSNR (rounded to 0.01 dB like problems/problem.py:33-35), read back once."""

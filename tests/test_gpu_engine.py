@@ -101,6 +101,38 @@ def test_device_minibatch_draw():
     assert (one.reshape(B, -1).sum(1) == 1).all()
 
 
+def _mb_hash_np(seed, step, prob, j):
+    """NumPy restatement of the draw's counter-based key (csmri.hip mb_hash: splitmix64 finaliser, high 32 bits)."""
+    with np.errstate(over='ignore'):
+        x = np.uint64(seed) ^ (np.uint64(step) << np.uint64(40)) ^ (np.uint64(prob) << np.uint64(20)) ^ j.astype(np.uint64)
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return (x >> np.uint64(32)).astype(np.uint32)
+
+
+@pytest.mark.parametrize('n,frac', [(64, 0.3), (256, 0.2), (256, 0.7)])
+def test_device_minibatch_draw_known_answer(n, frac):
+    """The draw is exactly "the mb smallest hash keys, ties by position" -- recomputed on the host.  256 x 256 at
+    70 % sampling (M0 = 45 875 keys) exceeds the LDS key cache and takes the re-hashing build of the kernel; the
+    other cases take the cached build."""
+    from pnp_svrg_amd import ops
+    B, mb, seed, step = 3, 777, 0xDEADBEEFCAFE, 12345
+    rng = np.random.default_rng(n)
+    M0 = int(round(frac * n * n))
+    idx = np.stack([np.sort(rng.choice(n * n, M0, replace=False)) for _ in range(B)]).astype(np.int32)
+    plan = ops.CsmriPlan(n, n, B, torch.float32)
+    sel = plan.draw_minibatch(torch.from_numpy(idx).cuda(), mb, seed=seed, step=step).cpu().numpy()
+    for b in range(B):
+        keys = _mb_hash_np(seed, step, b, np.arange(M0))
+        order = np.lexsort((np.arange(M0), keys))[:mb]
+        want = np.zeros((n, n), np.uint8)
+        i = idx[b][order]
+        want[i % n, i // n] = 1                                   # transposed selector [W][H]
+        assert np.array_equal(sel[b], want)
+
+
 def test_sweep_runner_single_process():
     """Config-5 shape in one process: images x sampling ratios batched through the engine; every item is
     reconstructed (PSNR improves) and results come back in canonical order with the CSV schema."""

@@ -268,6 +268,15 @@ __device__ __forceinline__ void wino_lds_load(f32x2v (&dd)[5][2], unsigned lds_b
 }
 // The wait takes the ten register pairs as in/out operands, so every consumer is data-dependent on it and no pass
 // can move a use of the (still in flight) load results above the s_waitcnt.
+// B^T d of one halo row as two packed-f32 adds: (d0-d2, -d1-d2) and (d1-d2, d1-d3).  The middle two components are
+// the NEGATED textbook ones (d1+d2, d2-d1); the inverse transform in the epilogue flips their signs back.  hipcc
+// lowers the first shuffle+negate to movs + two adds, so both are spelled out.  NO wait states inside: the caller
+// must put >= 2 instructions between this and the first MFMA that reads the results.
+__device__ __forceinline__ void wino_bt(f32x2v& v01, f32x2v& v23, f32x2v A, f32x2v Bq) {
+    asm volatile("v_pk_add_f32 %0, %2, %3 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]\n\t"
+                 "v_pk_add_f32 %1, %2, %3 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
+                 : "=&v"(v01), "=&v"(v23) : "v"(A), "v"(Bq));
+}
 __device__ __forceinline__ void wino_lds_wait(f32x2v (&dd)[5][2]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(dd[0][0]), "+v"(dd[0][1]), "+v"(dd[1][0]), "+v"(dd[1][1]), "+v"(dd[2][0]), "+v"(dd[2][1]),
@@ -348,10 +357,15 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
             f32x2v d[2][5][2];
             const unsigned xb_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + 4u * (unsigned)xb_off;
             wino_lds_load(d[0], xb_addr);
+            wino_lds_wait(d[0]);
+            // B^T d runs ONE ROW AHEAD of the MFMAs that consume it (software pipeline): the two packed adds of row
+            // i+1 issue before the 4-12 MFMAs of row i, so no wait states are needed between a VALU write and the
+            // MFMA that reads it (the hazard recognizer does not see inside the asm; pk -> MFMA needs 2).
+            f32x2v vc01, vc23;
+            wino_bt(vc01, vc23, d[0][0][0], d[0][0][1]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int c4 = g / 2, rb = g % 2;
-                wino_lds_wait(d[g & 1]);                        // d[g & 1] has landed
                 if (g + 1 < NG) {
                     const int c4n = (g + 1) / 2, rbn = (g + 1) % 2;
                     wino_lds_load(d[(g + 1) & 1], xb_addr + 4u * ((4 * c4n) * PLANE + (5 * rbn) * PC));
@@ -367,16 +381,15 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const int ry = 5 * rb + i;
-                    // B^T d as two packed-f32 ops: (d0-d2, -d1-d2) and (d1-d2, d1-d3).  The middle two components are
-                    // the NEGATED textbook ones (d1+d2, d2-d1); the inverse transform below flips their signs back.
-                    const f32x2v A = d[g & 1][i][0], Bq = d[g & 1][i][1];
-                    // hipcc lowers this shuffle+negate to movs + two adds, so it is spelled out.  The s_nop is REQUIRED:
-                    // a VALU write needs wait states before an MFMA reads it, and the hazard recognizer does not
-                    // look inside inline asm (without it the forward pass returns garbage -- measured).
-                    f32x2v v01;
-                    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]\n\ts_nop 1" : "=v"(v01) : "v"(A), "v"(Bq));
-                    const f32x2v v23 = f32x2v{A.y, A.y} - Bq;
-                    const float V[4] = {v01.x, v01.y, v23.x, v23.y};
+                    f32x2v vn01 = vc01, vn23 = vc23;
+                    if (i < 4) {
+                        wino_bt(vn01, vn23, d[g & 1][i + 1][0], d[g & 1][i + 1][1]);
+                    } else if (g + 1 < NG) {
+                        wino_lds_wait(d[(g + 1) & 1]);          // issued a whole group ago
+                        wino_bt(vn01, vn23, d[(g + 1) & 1][0][0], d[(g + 1) & 1][0][1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float V[4] = {vc01.x, vc01.y, vc23.x, vc23.y};
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const int r = ry - dy;
@@ -387,8 +400,9 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                                                                                    V[xi], acc[r][xi], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    vc01 = vn01; vc23 = vn23;
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_compute += t - tp; tp = t; }
             __syncthreads();

@@ -48,6 +48,8 @@ def parse():
                     help='gloo + PNP_BENCH_ONE_DEVICE=1 rehearses the N>1 path with all ranks on GPU 0')
     ap.add_argument('--graph', action='store_true',
                     help='replay one outer iteration (T2 steps) per hipGraph launch; --steps/--warmup are rounded up to multiples of T2')
+    ap.add_argument('--fused-tv', action='store_true',
+                    help='tv workload: pnp_csmri_grad_prox_tv (one kernel for step + noise estimate + prox; measured slower)')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
     return ap.parse_args()
 
@@ -111,7 +113,7 @@ def main():
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE {world}: using WORLD_SIZE', file=sys.stderr)
 
     from pnp_svrg_amd import ops
-    from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, DnCNNProx, TVProx
+    from pnp_svrg_amd.engine import CsmriBatch, make_engine, DnCNNProx, TVProx
     from pnp_svrg_amd.denoisers import random_dncnn_weights
     ops.require_gpu()
 
@@ -122,7 +124,7 @@ def main():
     wdesc = 'reference DnCNN_noise15 weights' if os.path.exists(wfile) else 'random-init weights'
     batch = CsmriBatch.synthetic(B, H, W, SAMPLE_PROB, SNR, seed=100 + rank)
     prox = DnCNNProx(weights, NET_SIGMA) if a.workload == 'dncnn' else TVProx()
-    eng = SvrgEngine(batch, prox, ETA, T2, MB, variant='svrg', seed=1 + rank)
+    eng = make_engine(batch, prox, ETA, T2, MB, variant='svrg', seed=1 + rank, fused=bool(a.fused_tv and a.workload == 'tv'))
     # minibatches are drawn ON THE DEVICE inside every step (pnp_csmri_draw_minibatch), like the reference
     # draws them inside its timed gradient phase (pnp_svrg.py:52); --host-minibatches pre-draws index lists
     n_draw = min(a.steps + a.warmup, 64)
@@ -189,7 +191,9 @@ def main():
         # no single dominant kernel (rows_inv / prox / cols / rows_fwd ~ 20-27 % each): the whole step against HBM
         alg = 2368 * 1024 * B                                    # 2 368 KiB per problem-iteration
         ach = alg / (dt / a.steps) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': 'whole inner iteration (k_rows_fwd + k_cols + k_rows_inv + k_prox_tv + k_draw_mb)',
+        kern = ('whole inner iteration (k_draw_mb + k_rows_fwd + k_cols + ' +
+                ('k_rows_inv_prox: step, noise estimate, prox and error fused)' if a.fused_tv else 'k_rows_inv + k_prox_tv)'))
+        roofline = {'bound': 'hbm', 'kernel': kern,
                     'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                     'traffic': None, 'bytes_per_step': alg}
 

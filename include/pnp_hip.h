@@ -67,6 +67,17 @@ int pnp_csmri_grad(pnp_csmri_plan* plan, const void* a, const void* b, const uin
                    const void* yh, double alpha, double beta, const void* c1,
                    double gamma, const void* c2, void* out, void* stream);
 
+/* pnp_csmri_grad immediately followed by the TV prox (pnp_prox_tv with the noise estimate fused, i.e.
+ * algorithms/pnp_svrg.py:53-80 = step, estimate_sigma, TVDenoiser.denoise, PSNR) in one pass over the image, for
+ * callers that keep their images TRANSPOSED: the prox acts along the STORAGE ROWS (last axis) of `out`, which are the
+ * image columns when a/b/c1/c2/out/xrec hold x^T (pass the selector and data term of the transposed problem, i.e. the
+ * un-transposed mask where pnp_csmri_grad wants the transposed one).  f32 plans, 64 x 64 or 256 x 256.
+ * sigma_modifier, fallback_sigma, xrec, sse_out, sigma_out as in pnp_prox_tv (sigma always estimated in-kernel).  */
+int pnp_csmri_grad_prox_tv(pnp_csmri_plan* plan, const void* a, const void* b, const uint8_t* selT, const void* yh,
+                           double alpha, double beta, const void* c1, double gamma, const void* c2, void* out,
+                           double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out,
+                           void* sigma_out, void* stream);
+
 /* ------------------------------------------------------------------ Deblur / super-resolution
  * Replaces problems/DeblurSR.py:119-147: 1-D circular blur of the raveled image via a length-H*W FFT
  * (spectrum of the kernel computed once at plan creation), optional 4-tap bilinear down-sampler

@@ -28,6 +28,7 @@ SIGNATURES = {
     'pnp_csmri_sel_from_dense': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_csmri_pack_y': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pnp_csmri_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _d, _vp, _vp, _vp]),
+    'pnp_csmri_grad_prox_tv': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _d, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp]),
     'pnp_deblur_plan_create': (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     'pnp_deblur_plan_destroy': (_i, [_vp]),
     'pnp_deblur_grad': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp]),

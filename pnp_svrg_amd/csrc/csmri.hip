@@ -15,7 +15,9 @@
 // "Packed": column kx=0 stores (X[.,0], X[.,W/2]) as (re,im) -- both are real after the row
 // pass -- so the half spectrum is exactly [W/2][H] complex = the bytes of the real image.
 #include "fft.h"
+#include "keys.h"
 #include <vector>
+#include <cstdlib>
 #include <cmath>
 
 namespace pnp {
@@ -181,6 +183,284 @@ __global__ __launch_bounds__(256) void k_rows_inv(const cx<T>* __restrict__ S1T,
             if (c2 != nullptr) { oa += gamma * c2[ra + w]; ob += gamma * c2[rb + w]; }
             out[ra + w] = oa;
             out[rb + w] = ob;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- rows inverse + line-wise TV prox
+// The last pass of the inverse transform leaves every NL-lane group holding two complete storage rows (element
+// lane + NL*r in register r).  When the caller keeps its images TRANSPOSED (storage row = image column) those rows
+// are exactly the lines the "TV" prox works along (per-column db2 noise estimate + multi-level Haar BayesShrink,
+// denoisers/TV.py:21-26 and estimate_sigma, see prox.hip), so the gradient step, the noise estimate, the prox and
+// the PSNR error run in ONE kernel: the stepped image never goes to HBM before it is denoised.  One workgroup owns
+// one image (the noise estimate is a mean over all of its lines).  Cross-lane steps are shuffles inside the NL-lane
+// group; arithmetic follows prox.hip product for product (no FMA contraction in the prox part).
+// MEASURED SLOWER than k_rows_inv + k_prox_tv (B = 256, 256 x 256: 281 vs 115 us) and therefore opt-in only: with
+// one 1024-thread workgroup per CU the phases run in lock step (no other workgroup hides a phase's memory latency:
+// the bare inverse pass takes 98 us here against 56 us as a streaming kernel), and the group shuffles compile to
+// ds_bpermute_b32 at ~32 LDS-pipe cycles per wave instruction (the Haar levels alone cost 118 us; DPP row shifts
+// would bring that to ~15 us, still short of break-even).  Kept as the measured negative result behind DESIGN 3.3.
+template <typename T, int NL> __device__ __forceinline__ T group_sum(T v) {
+#pragma unroll
+    for (int o = NL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, NL);
+    return v;
+}
+template <typename K, int NL> __device__ __forceinline__ K group_min(K v) {
+#pragma unroll
+    for (int o = NL / 2; o > 0; o >>= 1) { const K u = __shfl_xor(v, o, NL); v = u < v ? u : v; }
+    return v;
+}
+
+// MAD noise estimate of one line (all lanes of the group get it).  Odd lanes own the db2 detail coefficient of the
+// sample pair (2i, 2i+1) that ends on them; the coefficient past the end (symmetric extension) sits on the last lane.
+template <typename T, int NL>
+__device__ __forceinline__ T line_sigma(const T (&x)[NL], int lane) {
+#pragma clang fp contract(off)
+    using K = typename KeyOf<T>::type;
+    K key[NL + 1];
+    bool has_nan = false;
+    int n = 0;
+    const bool odd = (lane & 1) != 0;
+#pragma unroll
+    for (int r = 0; r <= NL; ++r) {
+        T d;
+        bool use;
+        if (r < NL) {
+            const T m1 = __shfl_up(x[r], 1, NL);
+            T m2 = __shfl_up(x[r], 2, NL), m3 = __shfl_up(x[r], 3, NL);
+            if (r > 0) {                                       // lane 1 reaches back into the previous register
+                const T w1 = __shfl(x[r - 1], NL - 1, NL), w2 = __shfl(x[r - 1], NL - 2, NL);
+                if (lane == 1) { m2 = w1; m3 = w2; }
+            } else if (lane == 1) {                            // start of the line: x[-1] = x[0], x[-2] = x[1]
+                m2 = m1; m3 = x[0];
+            }
+            d = ((Db2<T>::h0 * x[r] + Db2<T>::h1 * m1) + Db2<T>::h2 * m2) + Db2<T>::h3 * m3;
+            use = odd;
+        } else {                                               // end of the line: x[N] = x[N-1], x[N+1] = x[N-2]
+            const T own = x[NL - 1], m1 = __shfl_up(x[NL - 1], 1, NL);
+            d = ((Db2<T>::h0 * m1 + Db2<T>::h1 * own) + Db2<T>::h2 * own) + Db2<T>::h3 * m1;
+            use = lane == NL - 1;
+        }
+        d = d < 0 ? -d : d;
+        has_nan |= use && (d != d);
+        const bool nz = use && d != (T)0;
+        n += nz ? 1 : 0;
+        key[r] = nz ? to_key(d) : ~(K)0;                       // zeros (and non-owning lanes) are masked out
+    }
+    n = group_sum<int, NL>(n);
+    has_nan = group_sum<int, NL>((int)has_nan) != 0;
+    const int k = (n - 1) >> 1;
+    K pfx = 0;
+#pragma unroll 1
+    for (int bit = KeyOf<T>::BITS - 1; bit >= 0; --bit) {
+        const K cand = pfx | ((K)1 << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i <= NL; ++i) c += key[i] < cand ? 1 : 0;
+        c = group_sum<int, NL>(c);
+        if (c <= k) pfx = cand;
+    }
+    T med = from_key(pfx);
+    if ((n & 1) == 0) {
+        int cle = 0;
+        K nxt = ~(K)0;
+#pragma unroll
+        for (int i = 0; i <= NL; ++i) {
+            cle += key[i] <= pfx ? 1 : 0;
+            if (key[i] > pfx && key[i] < nxt) nxt = key[i];
+        }
+        cle = group_sum<int, NL>(cle);
+        nxt = group_min<K, NL>(nxt);
+        const T hi = cle > k + 1 ? med : from_key(nxt);
+        med = (med + hi) * (T)0.5;
+    }
+    if (n == 0 || has_nan) med = (T)NAN;
+    return med / (T)0.6744897501960817;
+}
+
+// Multi-level Haar BayesShrink of one line in place (levels as prox.hip: 5 for 256, 3 for 64).
+template <typename T, int NL>
+__device__ __forceinline__ void line_haar_shrink(T (&x)[NL], int lane, T var) {
+#pragma clang fp contract(off)
+    constexpr int N = NL * NL;
+    constexpr int L = N >= 256 ? 5 : N >= 128 ? 4 : N >= 64 ? 3 : N >= 32 ? 2 : 1;
+    constexpr T HA = (T)0.7071067811865476;
+    T thr[L];
+#pragma unroll
+    for (int lev = 0; lev < L; ++lev) {
+        const int s = 1 << lev;
+        T ss = 0;
+        if (s < NL) {                                          // partner sample lives s lanes away, same register
+            const bool ev = (lane & (2 * s - 1)) == 0, od = (lane & (2 * s - 1)) == s;
+#pragma unroll
+            for (int r = 0; r < NL; ++r) {
+                const T p = __shfl_xor(x[r], s, NL);
+                if (ev) x[r] = HA * p + HA * x[r];
+                else if (od) { const T d = -HA * x[r] + HA * p; x[r] = d; ss += d * d; }
+            }
+        } else if (lane == 0) {                                // partner is another register of lane 0
+            const int s2 = s / NL;
+#pragma unroll
+            for (int j = 0; j < NL / (2 * s2); ++j) {
+                const T e = x[2 * s2 * j], o = x[2 * s2 * j + s2];
+                const T d = -HA * o + HA * e;
+                x[2 * s2 * j] = HA * o + HA * e;
+                x[2 * s2 * j + s2] = d;
+                ss += d * d;
+            }
+        }
+        ss = group_sum<T, NL>(ss);
+        const T dvar = ss / (T)(N >> (lev + 1));
+        T den = dvar - var;
+        den = den > (T)2.220446049250313e-16 ? den : (T)2.220446049250313e-16;
+        thr[lev] = var / sqrt(den);
+    }
+#pragma unroll
+    for (int lev = L - 1; lev >= 0; --lev) {
+        const int s = 1 << lev;
+        if (s < NL) {
+            const bool ev = (lane & (2 * s - 1)) == 0, od = (lane & (2 * s - 1)) == s;
+#pragma unroll
+            for (int r = 0; r < NL; ++r) {
+                T val = x[r];
+                if (od) {
+                    const T mag = val < 0 ? -val : val;
+                    T shr = (T)1 - thr[lev] / mag;
+                    shr = shr < (T)0 ? (T)0 : shr;             // keeps NaN (0/0) like numpy clip
+                    val = val * shr;
+                }
+                const T p = __shfl_xor(val, s, NL);
+                if (ev) x[r] = HA * val + HA * p;
+                else if (od) x[r] = HA * p - HA * val;
+            }
+        } else if (lane == 0) {
+            const int s2 = s / NL;
+#pragma unroll
+            for (int j = 0; j < NL / (2 * s2); ++j) {
+                const T a = x[2 * s2 * j];
+                T d = x[2 * s2 * j + s2];
+                const T mag = d < 0 ? -d : d;
+                T shr = (T)1 - thr[lev] / mag;
+                shr = shr < (T)0 ? (T)0 : shr;
+                d = d * shr;
+                x[2 * s2 * j] = HA * a + HA * d;
+                x[2 * s2 * j + s2] = HA * a - HA * d;
+            }
+        }
+    }
+}
+
+template <int NL> struct FusedGeom {
+    static constexpr int N = NL * NL;                          // square images: H == W == N
+    static constexpr int THREADS = (N / 2) * NL > 1024 ? 1024 : (N / 2) * NL;
+    static constexpr int G = THREADS / NL;                     // complex rows in flight
+    static constexpr int IT = (N / 2) / G;                     // passes over the image
+    static constexpr int TILE = G * (N + 1), SCR = G * NL * (NL + 1);
+    static constexpr int ELEMS = TILE > SCR ? TILE : SCR;      // complex elements of dynamic LDS
+};
+
+template <typename T, int NL>
+__global__ __launch_bounds__(1024) void k_rows_inv_prox(const cx<T>* __restrict__ S1T, const cx<T>* __restrict__ twtab,
+                                                        T alpha, T beta, const T* c1, T gamma, const T* c2, T* out,
+                                                        T sigma_modifier, T fallback_sigma, const T* __restrict__ xrec,
+                                                        double* __restrict__ sse_out, T* __restrict__ sigma_out) {
+    using F = FusedGeom<NL>;
+    constexpr int N = F::N, G = F::G, IT = F::IT, H = F::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cx<T>* smem = reinterpret_cast<cx<T>*>(smem_raw);
+    __shared__ double red[16];
+    __shared__ T sig_sh;
+    const int t = threadIdx.x, g = t / NL, lane = t % NL, wv = t >> 6;
+    const int prob = blockIdx.x, p = t % G;
+    constexpr int NW = F::THREADS / 64;
+
+    T x[IT][2][NL];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int h0 = it * 2 * G;
+        if (it > 0) __syncthreads();
+        cx<T>* zp = smem + p * (N + 1);
+        for (int kx = t / G; kx < N / 2; kx += NL) {
+            const vec4<T> q = *reinterpret_cast<const vec4<T>*>(S1T + ((size_t)prob * (N / 2) + kx) * H + h0 + 2 * p);
+            if (kx == 0) {
+                zp[0] = {q.a, q.c};
+                zp[N / 2] = {q.b, q.d};
+            } else {
+                zp[kx] = {q.a - q.d, q.b + q.c};
+                zp[N - kx] = {q.a + q.d, q.c - q.b};
+            }
+        }
+        __syncthreads();
+        cx<T> v[NL], tw[NL];
+        load_twiddles_gen<T, NL>(tw, twtab, lane, N);
+#pragma unroll
+        for (int r = 0; r < NL; ++r) v[r] = smem[g * (N + 1) + lane + NL * r];
+        fft_gen<T, NL, NL, true>(v, tw, smem + g * NL * (NL + 1), lane);
+        const size_t ra = (size_t)prob * H * N + (size_t)(h0 + 2 * g) * N, rb = ra + N;
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+            const int w = lane + NL * r;
+            T oa = alpha * v[r].x, ob = alpha * v[r].y;
+            if (c1 != nullptr) { oa += beta * c1[ra + w]; ob += beta * c1[rb + w]; }
+            if (c2 != nullptr) { oa += gamma * c2[ra + w]; ob += gamma * c2[rb + w]; }
+            x[it][0][r] = oa;
+            x[it][1][r] = ob;
+        }
+    }
+
+    // ---------------- noise estimate: mean over the image's lines of the per-line MAD estimate
+    double part = 0.0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const T sc = line_sigma<T, NL>(x[it][j], lane);
+            part += lane == 0 ? (double)sc : 0.0;
+        }
+    part = wave_sum(part);
+    __syncthreads();
+    if ((t & 63) == 0) red[wv] = part;
+    __syncthreads();
+    if (t == 0) {
+        double s = 0;
+        for (int i = 0; i < NW; ++i) s += red[i];
+        sig_sh = (T)(s / (double)H);
+    }
+    __syncthreads();
+    const T sigma_est = sig_sh;
+    if (sigma_out != nullptr && t == 0) sigma_out[prob] = sigma_est;
+    const T sigma = sigma_est > (T)0 ? sigma_est * sigma_modifier : fallback_sigma;
+    const T var = sigma * sigma;
+
+    // ---------------- prox, error sum, store
+    double err = 0.0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            line_haar_shrink<T, NL>(x[it][j], lane, var);
+            const size_t row = (size_t)prob * H * N + (size_t)(it * 2 * G + 2 * g + j) * N;
+            if (xrec != nullptr) {
+                T e = 0;
+#pragma unroll
+                for (int r = 0; r < NL; ++r) {
+                    const T df = xrec[row + lane + NL * r] - x[it][j][r];
+                    e += df * df;
+                }
+                err += (double)e;
+            }
+#pragma unroll
+            for (int r = 0; r < NL; ++r) out[row + lane + NL * r] = x[it][j][r];
+        }
+    if (sse_out != nullptr) {
+        err = wave_sum(err);
+        __syncthreads();
+        if ((t & 63) == 0) red[wv] = err;
+        __syncthreads();
+        if (t == 0) {
+            double s = 0;
+            for (int i = 0; i < NW; ++i) s += red[i];
+            sse_out[prob] = s;
         }
     }
 }
@@ -470,4 +750,49 @@ extern "C" int pnp_csmri_grad(pnp_csmri_plan* p, const void* a, const void* b, c
     if (p->NL == 16) return run_grad<double, 16, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
     if (p->NL == 12) return run_grad<double, 8, 16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
     return run_grad<double, 8, 8>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, s);
+}
+
+namespace {
+template <int NL>
+int run_grad_prox(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const void* yh, double alpha,
+                  double beta, const void* c1, double gamma, const void* c2, void* out, double sigma_modifier,
+                  double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out, hipStream_t s) {
+    using T = float;
+    using F = FusedGeom<NL>;
+    constexpr int G = FftSmem<T, NL, NL>::G;
+    const int H = p->H, W = p->W;
+    cx<T>* work = (cx<T>*)p->work;
+    const cx<T>* tw = (const cx<T>*)p->twtab;
+    const T scale = (T)(alpha / ((double)H * (double)W));
+    k_rows_fwd<T, NL, NL><<<dim3(H / (2 * G), p->batch), 256, 0, s>>>((const T*)a, (const T*)b, work, tw, H);
+    PNP_CHECK_LAUNCH();
+    k_cols<T, NL, NL><<<dim3((W / 2) / G, p->batch), 256, 0, s>>>(work, selT, (const cx<T>*)yh, tw, W);
+    PNP_CHECK_LAUNCH();
+    constexpr size_t lds = (size_t)F::ELEMS * sizeof(cx<T>);
+    static bool attr_set = false;                               // > 64 KiB of dynamic LDS needs the opt-in, once
+    if (!attr_set) {
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_rows_inv_prox<T, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    k_rows_inv_prox<T, NL><<<p->batch, F::THREADS, lds, s>>>(work, tw, scale, (T)beta, (const T*)c1, (T)gamma, (const T*)c2,
+                                                            (T*)out, (T)sigma_modifier, (T)fallback_sigma, (const T*)xrec,
+                                                            sse_out, (T*)sigma_out);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+}  // namespace
+
+extern "C" int pnp_csmri_grad_prox_tv(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const void* yh,
+                                      double alpha, double beta, const void* c1, double gamma, const void* c2, void* out,
+                                      double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out,
+                                      void* sigma_out, void* stream) {
+    PNP_CHECK_ARG(p && a && selT && out, "null argument");
+    PNP_CHECK_ARG(!(sse_out && !xrec), "sse_out needs xrec");
+    PNP_CHECK_ARG(p->dtype == PNP_F32 && (p->NL == 16 || p->NL == 8), "fused gradient + prox: f32 plans of 64 x 64 or 256 x 256");
+    hipStream_t s = (hipStream_t)stream;
+    if (p->NL == 16)
+        return run_grad_prox<16>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, sigma_modifier, fallback_sigma, xrec,
+                                 sse_out, sigma_out, s);
+    return run_grad_prox<8>(p, a, b, selT, yh, alpha, beta, c1, gamma, c2, out, sigma_modifier, fallback_sigma, xrec, sse_out,
+                            sigma_out, s);
 }

@@ -14,34 +14,52 @@
 // written once.
 #include "common.h"
 #include "reduce.h"
+#include "keys.h"
 
 namespace pnp {
 
-template <typename T> struct KeyOf;
-template <> struct KeyOf<float> { using type = uint32_t; static constexpr int BITS = 31; };
-template <> struct KeyOf<double> { using type = uint64_t; static constexpr int BITS = 63; };
-
-__device__ __forceinline__ uint32_t to_key(float v) { return __float_as_uint(v); }
-__device__ __forceinline__ uint64_t to_key(double v) { return (uint64_t)__double_as_longlong(v); }
-__device__ __forceinline__ float from_key(uint32_t k) { return __uint_as_float(k); }
-__device__ __forceinline__ double from_key(uint64_t k) { return __longlong_as_double((long long)k); }
-
-// sum over the 4 lanes {l, l^16, l^32, l^48} that share a column
+// Reductions over the 4 lanes {l, l^16, l^32, l^48} that share a column, on gfx950's v_permlane16_swap /
+// v_permlane32_swap (VALU): swapping a register with a copy of itself leaves the even-row (lower-half) value in one
+// result and the odd-row (upper-half) value in the other, for both lanes of a pair.  A ds_bpermute shuffle costs ~32
+// LDS-pipe cycles per wave instruction, and the median's radix select does two of these reductions per bit.
+// Same pairing as (v + v^16) + (v^32 + v^48), so sums are bit-identical to the shuffle form.
+template <typename T> __device__ __forceinline__ void pair16(T v, T& a, T& b) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte values");
+    if constexpr (sizeof(T) == 4) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+        a = __builtin_bit_cast(T, (unsigned)r[0]); b = __builtin_bit_cast(T, (unsigned)r[1]);
+    } else {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+        a = __builtin_bit_cast(T, ((unsigned long long)hi[0] << 32) | lo[0]);
+        b = __builtin_bit_cast(T, ((unsigned long long)hi[1] << 32) | lo[1]);
+    }
+}
+template <typename T> __device__ __forceinline__ void pair32(T v, T& a, T& b) {
+    if constexpr (sizeof(T) == 4) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+        a = __builtin_bit_cast(T, (unsigned)r[0]); b = __builtin_bit_cast(T, (unsigned)r[1]);
+    } else {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+        a = __builtin_bit_cast(T, ((unsigned long long)hi[0] << 32) | lo[0]);
+        b = __builtin_bit_cast(T, ((unsigned long long)hi[1] << 32) | lo[1]);
+    }
+}
 template <typename T> __device__ __forceinline__ T col_sum(T v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    T a, b;
+    pair16(v, a, b); v = a + b;
+    pair32(v, a, b); v = a + b;
     return v;
 }
 template <typename K> __device__ __forceinline__ K col_min(K v) {
-    K u = __shfl_xor(v, 16, 64); v = u < v ? u : v;
-    u = __shfl_xor(v, 32, 64);   v = u < v ? u : v;
+    K a, b;
+    pair16(v, a, b); v = b < a ? b : a;
+    pair32(v, a, b); v = b < a ? b : a;
     return v;
 }
-
-template <typename T> struct Db2 {
-    static constexpr T h0 = (T)-0.48296291314453416, h1 = (T)0.8365163037378079,
-                       h2 = (T)-0.2241438680420134, h3 = (T)-0.12940952255126037;
-};
 
 // MAD sigma of one column from this lane's chunk x[0..RPC) (all 4 lanes of the column get it).
 template <typename T, int RPC>

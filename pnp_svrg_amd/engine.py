@@ -32,6 +32,7 @@ class CsmriBatch:
         self.maskT = self.plan.sel_from_dense(mask_u8)
         YT = torch.from_numpy(np.ascontiguousarray(np.swapaxes(Y, 1, 2))).to(device, cdt).contiguous()
         self.yh_full = self.plan.pack_y(YT, self.maskT)
+        self._Y_np = Y                                          # host copy: the fused-TV engine packs the transposed problem's data term
         self.inv_m0 = None
         if not np.all(self.M0 == self.M0[0]):
             # per-problem 1/M0 differs: fold it into the data (grad_full is linear in 1/M0)
@@ -40,6 +41,10 @@ class CsmriBatch:
         self.mask_np = np.ascontiguousarray(mask, np.uint8)
         # flatnonzero(mask) per problem (equal counts) for the device-side minibatch draw
         self.mask_idx = torch.from_numpy(np.stack([np.flatnonzero(m) for m in self.mask_np.reshape(B, -1)]).astype(np.int32)).to(device)
+
+    def Y_dev(self, cdt):
+        """the k-space data, un-transposed, on the device (complex [B, H, W])"""
+        return torch.from_numpy(np.ascontiguousarray(self._Y_np)).to(self.xrec.device, cdt).contiguous()
 
     @classmethod
     def synthetic(cls, B, H=256, W=256, sample_prob=0.2, snr=20.0, seed=0, dtype=torch.float32):
@@ -228,3 +233,96 @@ class SvrgEngine:
         sse = self.sse_log[:min(self.s, self.n_log)].cpu().numpy()
         with np.errstate(divide='ignore'):
             return np.around(10 * np.log10(1.0 / (sse / self.b.N)), 2)
+
+
+class SvrgEngineFusedTV(SvrgEngine):
+    """SvrgEngine for the TV prox with the inner iteration's last three stages in ONE kernel
+    (`pnp_csmri_grad_prox_tv`: SVRG step -> estimate_sigma -> Haar BayesShrink -> PSNR error).
+
+    The prox works along image columns, the last pass of the inverse FFT hands out storage rows; so this engine
+    keeps every image TRANSPOSED in HBM (z, w, mu, ground truth) and feeds the plan the transposed problem
+    (fft2(x^T) = fft2(x)^T: the un-transposed mask and data where the plain engine passes transposed ones).  `z`
+    reads back un-transposed.  Same minibatches, same results as SvrgEngine up to the summation order of the
+    wavelet sub-band energies (~1e-6); the stepped image never travels to HBM between gradient and prox.
+    Opt-in (`make_engine(..., fused=True)`): on MI355X the one-workgroup-per-image kernel is measured SLOWER than
+    the two streaming kernels it replaces (csmri.hip, k_rows_inv_prox), so the plain engine stays the default."""
+
+    @staticmethod
+    def eligible(batch, prox, variant='svrg'):
+        return (isinstance(prox, TVProx) and variant == 'svrg' and batch.dtype == torch.float32
+                and batch.H == batch.W and batch.H in (64, 256))
+
+    def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096, seed=0):
+        assert self.eligible(batch, prox, variant), 'fused TV engine: TVProx, true SVRG, float32, 64x64 or 256x256'
+        self.b, self.prox, self.eta, self.T2, self.mb, self.lr_decay, self.variant = batch, prox, eta, T2, mini_batch_size, lr_decay, variant
+        dev = batch.xrec.device
+        tr = lambda a: a.transpose(1, 2).contiguous()
+        self._zT = tr(batch.xinit)
+        self._wT = torch.empty_like(self._zT)
+        self._muT = torch.empty_like(self._zT)
+        self._xrecT = tr(batch.xrec)
+        # the transposed problem: its "transposed selector" is the plain mask, its data term is packed from Y itself
+        self._mask = torch.from_numpy(batch.mask_np).to(dev)
+        cdt = torch.complex64
+        self._yh_full = batch.plan.pack_y(batch.Y_dev(cdt), self._mask)
+        self._mask_idxT = self._tidx(batch.mask_idx)            # same order as mask_idx -> the same draws
+        self.selT = torch.empty_like(self._mask)
+        self.sse_log = torch.zeros((n_log, batch.B), dtype=torch.float64, device=dev)
+        self.n_log, self.seed, self.s = n_log, seed, 0
+        prox.bind(batch)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._dev_step = 0
+        self.sse_tmp = torch.zeros(batch.B, dtype=torch.float64, device=dev)
+        self.graph = None
+
+    def _tidx(self, idx):
+        """flat row-major index into H x W -> flat index of the same location in the transposed W x H array"""
+        H, W = self.b.H, self.b.W
+        return ((idx % W) * H + idx // W).to(torch.int32)
+
+    z = property(lambda self: self._zT.transpose(1, 2))
+    w = property(lambda self: self._wT.transpose(1, 2))
+    mu = property(lambda self: self._muT.transpose(1, 2))
+
+    def _refresh(self):
+        b = self.b
+        b.plan.grad(self._zT, self._mask, yh=self._yh_full, alpha=1.0 / float(b.M0[0]), out=self._muT)
+        self._wT.copy_(self._zT)
+
+    def _inner(self, lr, sse_out):
+        b, px = self.b, self.prox
+        px.t += 1
+        b.plan.grad_prox_tv(self._zT, self.selT, b=self._wT, alpha=-lr / self.mb, beta=1.0, c1=self._zT, gamma=-lr,
+                            c2=self._muT, out=self._zT, sigma_modifier=px.sigma_modifier,
+                            fallback_sigma=px.denoise_strength * px.decay ** px.t, xrec=self._xrecT, sse=sse_out,
+                            sigma_out=px.sig)
+
+    def step(self, idx_s=None):
+        b, s = self.b, self.s
+        if s % self.T2 == 0:
+            self._refresh()
+        lr = self.eta * self.lr_decay ** (s // self.T2)
+        if idx_s is None:
+            b.plan.draw_minibatch(self._mask_idxT, self.mb, self.seed, s, out=self.selT)
+        else:
+            b.plan.sel_from_indices(self._tidx(idx_s), out=self.selT)
+        self._inner(lr, self.sse_log[s % self.n_log])
+        self.s += 1
+
+    def _outer_body(self):
+        b = self.b
+        self._refresh()
+        for _ in range(self.T2):
+            b.plan.draw_minibatch(self._mask_idxT, self.mb, self.seed, 0, out=self.selT, step_dev=self.step_dev)
+            self._inner(self.eta, self.sse_tmp)
+            ops.log_append(self.sse_tmp, self.sse_log, self.step_dev)
+            ops.counter_add(self.step_dev, 1)
+
+
+def make_engine(batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', fused=None, **kw):
+    """SvrgEngine (default: the faster form, see SvrgEngineFusedTV), or SvrgEngineFusedTV when fused=True."""
+    ok = SvrgEngineFusedTV.eligible(batch, prox, variant)
+    if fused and not ok:
+        raise ValueError('fused TV engine needs TVProx, variant="svrg", float32 and 64x64 or 256x256 images')
+    cls = SvrgEngineFusedTV if fused else SvrgEngine
+    return cls(batch, prox, eta, T2, mini_batch_size, lr_decay=lr_decay, variant=variant, **kw)

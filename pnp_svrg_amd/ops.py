@@ -81,6 +81,19 @@ class CsmriPlan:
                float(gamma), _p(c2), _p(out), _stream())
         return out
 
+    def grad_prox_tv(self, a, selT, b=None, yh=None, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None,
+                     sigma_modifier=1.0, fallback_sigma=0.0, xrec=None, sse=None, sigma_out=None):
+        """pnp_csmri_grad_prox_tv: `grad` immediately followed by the TV prox along the LAST axis of the stored
+        arrays (callers keep their images transposed), one pass over the image.  Returns (out, sse, sigma_est)."""
+        out = out if out is not None else torch.empty_like(a)
+        if xrec is not None and sse is None:
+            sse = torch.empty(self.B, dtype=torch.float64, device=a.device)
+        sigma_out = sigma_out if sigma_out is not None else torch.empty(self.B, dtype=a.dtype, device=a.device)
+        N.call('pnp_csmri_grad_prox_tv', self._h, _p(a), _p(b), _p(selT), _p(yh), float(alpha), float(beta), _p(c1),
+               float(gamma), _p(c2), _p(out), float(sigma_modifier), float(fallback_sigma), _p(xrec), _p(sse),
+               _p(sigma_out), _stream())
+        return out, sse, sigma_out
+
 
 class DncnnPlan:
     """pnp_dncnn_plan_*: DnCNN-17 prox for B images of H x W (fp32 network on the f32 matrix cores).

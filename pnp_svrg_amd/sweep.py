@@ -60,7 +60,7 @@ def csmri_svrg_runner(images, denoiser_factory, eta, T2, mini_batch_size, n_inne
                       max_batch=64):
     """Default runner: CSMRI + pnp_svrg (true SVRG direction) on the batched engine.
     images: list of HxW arrays; items with the same alpha are batched together (equal M0 per batch)."""
-    from .engine import CsmriBatch, SvrgEngine
+    from .engine import CsmriBatch, make_engine
 
     def run(items):
         results = []
@@ -85,7 +85,7 @@ def csmri_svrg_runner(images, denoiser_factory, eta, T2, mini_batch_size, n_inne
                     xi = np.absolute(np.fft.ifft2(Y))
                     xs.append(x); masks.append(mk); Ys.append(Y); xinits.append((xi - xi.min()) / (xi.max() - xi.min()))
                 batch = CsmriBatch(np.stack(xs), np.stack(masks), np.stack(Ys), np.stack(xinits).reshape(len(chunk), -1), dtype=dtype)
-                eng = SvrgEngine(batch, denoiser_factory(), eta, T2, mini_batch_size, variant='svrg')
+                eng = make_engine(batch, denoiser_factory(), eta, T2, mini_batch_size, variant='svrg')
                 idx = batch.draw_minibatches(n_inner, mini_batch_size, seed=chunk[0]['id'] + 1)
                 for s in range(n_inner):
                     eng.step(idx[s])

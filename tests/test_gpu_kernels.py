@@ -156,3 +156,47 @@ def test_minmax_axpby(ops):
     t64 = dev(x, torch.float64)
     r = ops.axpbypcz(2.0, t64, -0.5, y, 0.25, t64)
     np.testing.assert_allclose(r.cpu().numpy(), 2.25 * x - 0.5 * y.cpu().numpy(), atol=1e-14)
+
+
+@pytest.mark.parametrize('n', [64, 256])
+def test_fused_grad_prox_tv_equals_two_kernels(ops, n):
+    """pnp_csmri_grad_prox_tv (one pass: SVRG step -> noise estimate -> Haar BayesShrink along the storage rows ->
+    squared error) == pnp_csmri_grad followed by pnp_prox_tv on the transposed arrays.  The noise estimate is
+    bit-identical (same products, exact median); the shrink differs only by the summation order of the sub-band
+    energies."""
+    rng = np.random.default_rng(n)
+    B = 3
+    plan = ops.CsmriPlan(n, n, B, torch.float32)
+    p = np.pad(rng.random((B, n, n)), ((0, 0), (2, 2), (2, 2)), mode='wrap')
+    smooth = sum(p[:, i:i + n, j:j + n] for i in range(5) for j in range(5)) / 25.0
+    xrec = dev(smooth, torch.float32)
+    z = dev(smooth + 0.05 * rng.standard_normal((B, n, n)), torch.float32)
+    w = dev(smooth + 0.05 * rng.standard_normal((B, n, n)), torch.float32)
+    mu = dev(1e-4 * rng.standard_normal((B, n, n)), torch.float32)
+    sel = dev((rng.random((B, n, n)) < 0.03).astype(np.uint8))
+    lr, mb = 1e3, 120.0
+    kw = dict(b=w, alpha=-lr / mb, beta=1.0, c1=z, gamma=-lr, c2=mu)
+    stepped = plan.grad(z, sel, **kw)
+    T = lambda a: a.transpose(1, 2).contiguous()
+    want, want_sse, want_sig = ops.prox_tv(T(stepped), xrec=T(xrec), sigma_modifier=1.3)
+    got, sse, sig = plan.grad_prox_tv(z, sel, xrec=xrec, sigma_modifier=1.3, **kw)
+    assert torch.equal(sig, want_sig)                                   # identical noise estimate
+    assert float(sig.min()) > 0
+    d = (got - T(want)).abs().max().item()
+    assert d <= 2e-6, d
+    assert not torch.equal(got, stepped)                                # the prox did something
+    np.testing.assert_allclose(sse.cpu().numpy(), want_sse.cpu().numpy(), rtol=1e-5)
+    # in place (out aliases a and c1, as the engine calls it) and without the error sum
+    z2 = z.clone()
+    plan.grad_prox_tv(z2, sel, b=w, alpha=-lr / mb, beta=1.0, c1=z2, gamma=-lr, c2=mu, out=z2, sigma_modifier=1.3)
+    assert torch.equal(z2, got)
+    # sigma == 0 -> fallback threshold path (constant image: every detail coefficient is zero -> NaN estimate
+    # is NOT > 0, fallback_sigma is used, exactly like the two-kernel path)
+    c = torch.full((B, n, n), 0.25, dtype=torch.float32, device='cuda')
+    zero_sel = torch.zeros_like(sel)
+    a1, _, s1 = plan.grad_prox_tv(c, zero_sel, alpha=1.0, beta=1.0, c1=c, fallback_sigma=0.1)
+    b1, _, s2 = ops.prox_tv(T(plan.grad(c, zero_sel, alpha=1.0, beta=1.0, c1=c)), fallback_sigma=0.1)
+    assert torch.equal(torch.isnan(s1), torch.isnan(s2))
+    assert torch.equal(torch.isnan(a1), torch.isnan(T(b1)))
+    m = ~torch.isnan(a1)
+    assert (a1[m] - T(b1)[m]).abs().max().item() <= 2e-6 if m.any() else True

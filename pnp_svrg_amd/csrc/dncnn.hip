@@ -309,14 +309,17 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
 #pragma unroll
     for (int r = 0; r < 4; ++r) loff[r] = (16 * wv + 4 * (lane >> 4) + r) * H * W + 2 * (lane & 15);
 
-    int poff[PIECES_PER_WAVE], prc[PIECES_PER_WAVE];           // DMA piece descriptors (see k_mid)
+    // DMA piece descriptors, ONE register each: bits 0..27 = element offset of the lane's 16-byte chunk inside the
+    // half's 32 channel planes, bits 28..31 = which image edge would put the chunk outside (top row of the halo,
+    // bottom row, left chunk, right chunk).  A tile's own edge mask (scalar) then decides validity with one AND.
+    unsigned pdesc[PIECES_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < PIECES_PER_WAVE; ++i) {
         const int q = (wv + 4 * i) * 64 + lane;
         const int cin = q / 100, r = q - cin * 100;
         const int ry = r / 10, cx4 = 4 * (r - ry * 10);
-        prc[i] = ry | (cx4 << 8);
-        poff[i] = (cin * H + ry) * W + cx4;
+        const unsigned edge = (ry == 0 ? 1u : 0u) | (ry == TR + 1 ? 2u : 0u) | (cx4 == 0 ? 4u : 0u) | (cx4 == TC + 4 ? 8u : 0u);
+        pdesc[i] = (unsigned)((cin * H + ry) * W + cx4) | (edge << 28);
     }
 
     int tile = blockIdx.x;
@@ -346,10 +349,10 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
             const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
             const bool nvalid = half == 0 ? true : nt < ntiles;
             const float* nsrc0 = in + (((size_t)nb * C + (half ^ 1) * HALF_C) * H + nty0 - 1) * (size_t)W + ntx0 - 4;
+            const unsigned nedge = ((nty0 == 0 ? 1u : 0u) | (nty0 + TR == H ? 2u : 0u) | (ntx0 == 0 ? 4u : 0u) | (ntx0 + TC == W ? 8u : 0u)) << 28;
 
             int xb_off = half * HALF_LDS + lbase;
             asm volatile("" : "+v"(xb_off));
-            const float* xb = lds + xb_off;
             if (STAMP) tp = __builtin_amdgcn_s_memtime();
 
             // group = (channel quad c4, block of 5 halo rows): 10 ds_read2 + 20 transform ops + 48 MFMAs
@@ -372,9 +375,8 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                 }
                 if (g < PIECES_PER_WAVE) {
                     const int pc = wv + 4 * g;
-                    const int y = nty0 - 1 + (prc[g] & 255), x = ntx0 - 4 + (prc[g] >> 8);
-                    const bool ok = nvalid & (pc < PIECES) & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
-                    const float* src = ok ? nsrc0 + poff[g] : zeros;
+                    const bool ok = (nvalid & (pc < PIECES)) & ((pdesc[g] & nedge) == 0u);
+                    const float* src = ok ? nsrc0 + (pdesc[g] & 0x0FFFFFFFu) : zeros;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(nbuf + pc * 256), 16, 0, 0);
                 }

@@ -277,6 +277,19 @@ __device__ __forceinline__ void wino_bt(f32x2v& v01, f32x2v& v23, f32x2v A, f32x
                  "v_pk_add_f32 %1, %2, %3 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
                  : "=&v"(v01), "=&v"(v23) : "v"(A), "v"(Bq));
 }
+// The Winograd kernel's MFMAs are hand-issued so that the REGISTER FILES are split the other way round from what
+// hipcc picks: accumulators in VGPRs (the epilogue's VALU reads them in place), the 192 tile-invariant transformed
+// weights in AGPRs (gfx90a+ MFMAs read SrcA from either file).  hipcc keeps accumulators in AGPRs, copies ~60
+// weights through v_accvgpr_read every tile and reads all 128 accumulators back for the epilogue.  The first MFMA
+// of an accumulator in a tile uses the constant-zero SrcC form, so accumulators are never cleared.
+// Hazards are the caller's: >= 2 instructions between a VALU write of `v` and the MFMA, and wait states between the
+// last MFMA and a VALU read of an accumulator (the hazard recognizer does not look inside inline asm).
+__device__ __forceinline__ void mfma_wa(f32x4& acc, float w_agpr, float v) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(w_agpr), "v"(v));
+}
+__device__ __forceinline__ void mfma_wa_first(f32x4& acc, float w_agpr, float v) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "a"(w_agpr), "v"(v));
+}
 __device__ __forceinline__ void wino_lds_wait(f32x2v (&dd)[5][2]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(dd[0][0]), "+v"(dd[0][1]), "+v"(dd[1][0]), "+v"(dd[1][1]), "+v"(dd[2][0]), "+v"(dd[2][1]),
@@ -334,11 +347,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
-        f32x4 acc[TR][4];
-#pragma unroll
-        for (int r = 0; r < TR; ++r)
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi) acc[r][xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[TR][4];                                       // written first by mfma_wa_first (half 0, channel quad 0, dy 0)
 
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -397,9 +406,11 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                         const int r = ry - dy;
                         if (r >= 0 && r < TR) {
 #pragma unroll
-                            for (int xi = 0; xi < 4; ++xi)
-                                acc[r][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ureg[((half * (HALF_C / 4) + c4) * 3 + dy) * 4 + xi],
-                                                                                   V[xi], acc[r][xi], 0, 0, 0);
+                            for (int xi = 0; xi < 4; ++xi) {
+                                const float wgt = ureg[((half * (HALF_C / 4) + c4) * 3 + dy) * 4 + xi];
+                                if (half == 0 && c4 == 0 && dy == 0) mfma_wa_first(acc[r][xi], wgt, V[xi]);
+                                else mfma_wa(acc[r][xi], wgt, V[xi]);
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -412,6 +423,9 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
         }
 
         // epilogue: inverse transform, bias (+ReLU); a lane holds pixel pair (2j, 2j+1) of 4 channels per row
+        // (the barrier above sits between the last MFMA and these VALU reads; the explicit wait states make the
+        // MFMA-write -> VALU-read distance independent of what the barrier costs)
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
         float* ob = out + (size_t)b * C * H * W + ty0 * W + tx0;
 #pragma unroll
         for (int r = 0; r < TR; ++r) {

@@ -661,10 +661,11 @@ __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T*
 
 // ------------------------------------------------------------------------------- last layer
 // r = sum_{c,t} w[c][t] * act[c][tap t];  x = xt - r;  x = (x - sshift)/srange;  z = x*(hi-lo)+lo
-// HBM/L2-bound (reads the 64-channel activation once): 16 x 64 output tile per workgroup, 8 channels
-// at a time staged in LDS as [8][18][72] (columns tx0-4 .. tx0+67, 16-byte aligned rows), every
+// HBM/L2-bound (reads the 64-channel activation once): 16 x 64 output tile per workgroup, 4 channels
+// at a time staged in LDS as [4][18][72] (columns tx0-4 .. tx0+67, 16-byte aligned rows; 21 KB, so a whole
+// B = 16 grid of 1024 workgroups is resident at once), the next slab's loads in flight during the current one, every
 // thread owns a 1 x 4 pixel strip: one ds_read_b128 + two ds_read_b32 per row and channel.
-constexpr int LT_R = 16, LT_C = 64, LT_CK = 8, LT_PR = LT_R + 2, LT_PC = LT_C + 8;
+constexpr int LT_R = 16, LT_C = 64, LT_CK = 4, LT_PR = LT_R + 2, LT_PC = LT_C + 8;
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_last(const float* __restrict__ act, const float* __restrict__ w,
@@ -682,19 +683,36 @@ __global__ __launch_bounds__(256) void k_last(const float* __restrict__ act, con
     const int py = tid >> 4, px = (tid & 15) * 4;               // this thread's strip inside the tile
     const float* ab = act + (size_t)b * C * H * W;
     float r[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < C; c0 += LT_CK) {
-        __syncthreads();
-        // stage [8 ch][18 rows][18 float4]
-        for (int i = tid; i < LT_CK * LT_PR * (LT_PC / 4); i += 256) {
-            const int ch = i / (LT_PR * (LT_PC / 4)), rem = i - ch * (LT_PR * (LT_PC / 4));
-            const int ry = rem / (LT_PC / 4), cx = rem - ry * (LT_PC / 4);
-            const int y = ty0 - 1 + ry, x = tx0 - 4 + 4 * cx;
+    // software pipeline over the 8-channel slabs: the global loads of slab k+1 are in flight (in registers) while
+    // slab k is consumed out of LDS, so a workgroup never sits on an exposed HBM round trip per slab
+    constexpr int SLAB = LT_CK * LT_PR * (LT_PC / 4);          // float4 elements of one slab (2592)
+    constexpr int PER_T = (SLAB + 255) / 256;                  // 11 per thread
+    float4 pre[PER_T];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < PER_T; ++k) {
+            const int i = tid + 256 * k;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y >= 0 && y < H && x >= 0 && x < W)
-                v = *reinterpret_cast<const float4*>(ab + ((size_t)(c0 + ch) * H + y) * W + x);
-            *reinterpret_cast<float4*>(tile + (ch * LT_PR + ry) * LT_PC + 4 * cx) = v;
+            if (i < SLAB) {
+                const int ch = i / (LT_PR * (LT_PC / 4)), rem = i - ch * (LT_PR * (LT_PC / 4));
+                const int ry = rem / (LT_PC / 4), cx = rem - ry * (LT_PC / 4);
+                const int y = ty0 - 1 + ry, x = tx0 - 4 + 4 * cx;
+                if (y >= 0 && y < H && x >= 0 && x < W)
+                    v = *reinterpret_cast<const float4*>(ab + ((size_t)(c0 + ch) * H + y) * W + x);
+            }
+            pre[k] = v;
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < C; c0 += LT_CK) {
+        __syncthreads();                                        // the previous slab has been consumed
+#pragma unroll
+        for (int k = 0; k < PER_T; ++k) {
+            const int i = tid + 256 * k;
+            if (i < SLAB) reinterpret_cast<float4*>(tile)[i] = pre[k];   // slab layout == linear float4 index
         }
         __syncthreads();
+        if (c0 + LT_CK < C) fetch(c0 + LT_CK);
 #pragma unroll
         for (int ch = 0; ch < LT_CK; ++ch) {
             const float* wc = ws + (c0 + ch) * 9;

@@ -26,6 +26,7 @@
 //   * per wave and phase: 576 MFMAs (64 cycles each) vs 576 ds_read_b32 + 43 global loads: the
 //     matrix pipe is the only busy resource by a wide margin.
 #include "common.h"
+#include "f16x3.h"
 #include "reduce.h"
 #include <vector>
 #include <algorithm>
@@ -788,6 +789,7 @@ using namespace pnp;
 struct pnp_dncnn_plan {
     int n_mid, H, W, batch, num_cu;
     float *w_first, *w_last, *wpack, *upack, *bias;   // device (upack: Winograd F(2,3)-transformed weights)
+    void* wpack16;                               // split-fp16 weight fragments (mode 3, dncnn_f16x3.hip)
     float* b_first;                              // [64] device, zeros unless pnp_dncnn_set_affine
     float b_last, slope;                         // last-layer bias, LeakyReLU slope (0 = ReLU)
     int use_wino;
@@ -855,6 +857,12 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e == hipSuccess) e = hipMemcpy(p->w_first, w_first, C * 9 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->w_last, C * 9 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->w_last, w_last, C * 9 * sizeof(float), hipMemcpyHostToDevice);
+    {
+        std::vector<unsigned char> w16(f16x3_weight_bytes(n_mid));
+        f16x3_pack_weights(w_mid, n_mid, w16.data());
+        if (e == hipSuccess) e = hipMalloc(&p->wpack16, w16.size());
+        if (e == hipSuccess) e = hipMemcpy(p->wpack16, w16.data(), w16.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&p->b_first, C * sizeof(float));
     if (e == hipSuccess) e = hipMemset(p->b_first, 0, C * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&p->act0, act_bytes);
@@ -866,7 +874,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e != hipSuccess) {
         set_error(std::string("pnp_dncnn_plan_create: ") + hipGetErrorString(e));
         for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
-                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first})
+                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16})
             if (q) (void)hipFree(q);
         delete p;
         return PNP_ERR_HIP;
@@ -878,7 +886,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
 extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
     if (!p) return PNP_OK;
     for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
-                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first})
+                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16})
         (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -906,8 +914,17 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     float *src = p->act0, *dst = p->act1;
     const bool prof = p->profile && p->ev_used + 2 <= p->ev.size();
     if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
+    if (p->use_wino == 3) {                                     // opt-in split-fp16 layers (dncnn_f16x3.hip)
+        int rc = f16x3_to_a16(src, dst, H, W, B, s);
+        if (rc != PNP_OK) return rc;
+        float* t = src; src = dst; dst = t;
+    }
     for (int l = 0; l < p->n_mid; ++l) {
-        if (p->slope != 0.f) {                             // LeakyReLU builds exist for the two production kernels
+        if (p->use_wino == 3) {
+            const int rc = f16x3_layer(src, dst, (const unsigned char*)p->wpack16 + f16x3_weight_bytes(1) * (size_t)l,
+                                       p->bias + (size_t)l * C, p->zeros, H, W, B, p->num_cu, l == p->n_mid - 1, p->slope, s);
+            if (rc != PNP_OK) return rc;
+        } else if (p->slope != 0.f) {                             // LeakyReLU builds exist for the two production kernels
             if (p->use_wino)
                 k_mid_wino<true, false, true><<<grid, 256, 0, s>>>(src, dst, p->upack + (size_t)l * 4 * WINO_U * 64,
                                                                   p->bias + (size_t)l * C, p->zeros, H, W, ntiles, nullptr, p->slope);

@@ -155,3 +155,28 @@ def test_mmo_device_batch_and_sse():
         assert np.abs(single - o[b]).max() <= 1e-6
     ref = ((xrec.cpu().numpy() - o) ** 2).sum(axis=(1, 2))
     assert np.allclose(sse.cpu().numpy(), ref, rtol=1e-10, atol=1e-12)
+
+
+def test_split_fp16_conv_mode(W15, io):
+    """Opt-in mode 3 (dncnn_f16x3.hip): every fp32 operand split into two fp16 terms, three fp16 MFMAs per product
+    with fp32 accumulation.  Bounds its deviation (a) from the reference network's own output with the same 2e-5
+    bound the fp32 kernels meet, (b) from the direct fp32 kernel, on square, rectangular and batched inputs; and the
+    whole denoise() wrapper."""
+    from pnp_svrg_amd import ops
+    for n in (64, 256):
+        x = dev(io[f'net{n}_in'][None])
+        r3 = ops.DncnnPlan(W15, n, n, 1, winograd=3).forward(x).cpu().numpy()[0]
+        r0 = ops.DncnnPlan(W15, n, n, 1, winograd=0).forward(x).cpu().numpy()[0]
+        ref = io[f'net{n}_out']
+        e_ref, e_f32 = np.abs(r3 - ref).max(), np.abs(r3 - r0).max()
+        print(f'split-fp16 {n}x{n}: max |.-reference| {e_ref:.2e} (fp32 direct kernel: {np.abs(r0 - ref).max():.2e}), max |.-fp32 kernel| {e_f32:.2e}')
+        assert e_ref <= 2e-5 and e_f32 <= 2e-5
+    rng = np.random.default_rng(1)
+    xb = rng.random((3, 40, 96)).astype(np.float32)
+    r3 = ops.DncnnPlan(W15, 40, 96, 3, winograd=3).forward(dev(xb)).cpu().numpy()
+    for i in range(3):
+        assert np.abs(r3[i] - od.dncnn_forward(W15, xb[i])).max() <= 2e-5
+    z = dev(io['net64_in'][None] * 0.8 + 0.1, torch.float64)
+    a, _ = ops.DncnnPlan(W15, 64, 64, 1, winograd=3).denoise(z, 15.0)
+    b, _ = ops.DncnnPlan(W15, 64, 64, 1, winograd=0).denoise(z, 15.0)
+    assert (a - b).abs().max().item() <= 2e-5

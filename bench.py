@@ -33,6 +33,7 @@ ETA, T2, MB = 2e3, 10, 1000
 NET_SIGMA = 15
 FLOP_MID_PER_IMAGE = 2 * 9 * 64 * 64 * H * W          # one 64->64 3x3 conv layer
 F32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+F16_MFMA_PEAK_TFLOPS = 2500.0                         # same guide: ~2.5 PF dense bf16/f16 (only for --conv f16x3)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -48,6 +49,10 @@ def parse():
                     help='gloo + PNP_BENCH_ONE_DEVICE=1 rehearses the N>1 path with all ranks on GPU 0')
     ap.add_argument('--graph', action='store_true',
                     help='replay one outer iteration (T2 steps) per hipGraph launch; --steps/--warmup are rounded up to multiples of T2')
+    ap.add_argument('--conv', default=None, choices=['f32-winograd', 'f32-direct', 'f16x3'],
+                    help='conv kernel of the DnCNN prox (default: f32-winograd, or PNP_DNCNN_WINOGRAD).  f16x3 = opt-in '
+                         'split-fp16 products with fp32 accumulation (fp32-class accuracy, not the reference arithmetic): '
+                         'the line then says dtype "f32 via 3 x f16 split" and prices the conv against the f16 matrix peak')
     ap.add_argument('--fused-tv', action='store_true',
                     help='tv workload: pnp_csmri_grad_prox_tv (one kernel for step + noise estimate + prox; measured slower)')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
@@ -112,6 +117,8 @@ def main():
     if a.gpus != world and rank == 0 and world > 1:
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE {world}: using WORLD_SIZE', file=sys.stderr)
 
+    if a.conv is not None:
+        os.environ['PNP_DNCNN_WINOGRAD'] = {'f32-winograd': '1', 'f32-direct': '0', 'f16x3': '3'}[a.conv]
     from pnp_svrg_amd import ops
     from pnp_svrg_amd.engine import CsmriBatch, make_engine, DnCNNProx, TVProx
     from pnp_svrg_amd.denoisers import random_dncnn_weights
@@ -174,8 +181,19 @@ def main():
                 traffic = json.load(open(tj)).get(f'k_mid_B{B}')
             except Exception:
                 traffic = None
-        wino = os.environ.get('PNP_DNCNN_WINOGRAD', '1') != '0'
-        roofline = {'bound': 'mfma',
+        mode = os.environ.get('PNP_DNCNN_WINOGRAD', '1')
+        wino = mode not in ('0', '3')
+        if mode == '3':
+            executed = 3.0 * ach                                # three fp16 MFMAs per product
+            roofline = {'bound': 'mfma',
+                        'kernel': 'pnp::k_mid_f16x3 (64->64 3x3 conv, every fp32 operand split into two fp16 terms, three '
+                                  'v_mfma_f32_16x16x32_f16 per product, fp32 accumulation; OPT-IN, not the reference arithmetic)',
+                        'achieved': round(executed, 2), 'peak': F16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(executed / F16_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                        'launch_ms': round(ms, 4), 'launches_timed': launches, 'flops_per_launch': 3 * flops,
+                        'algorithmic_tflops': round(ach, 2)}
+        else:
+          roofline = {'bound': 'mfma',
                     'kernel': ('pnp::k_mid_wino (64->64 3x3 conv, Winograd F(2,3) along x on v_mfma_f32_16x16x4_f32: 2/3 of the '
                                'direct form\'s multiply-adds, so the ALGORITHMIC rate can exceed the matrix-core peak)') if wino
                               else 'pnp::k_mid (64->64 3x3 conv, direct implicit GEMM on v_mfma_f32_16x16x4_f32)',
@@ -218,7 +236,9 @@ def main():
                       else 'PnP-SVRG inner-iters/sec, 256x256 CSMRI+TV',
             'value': round(value, 2), 'unit': 'inner-iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'f32 via 3 x f16 split products (opt-in)' if (a.workload == 'dncnn' and os.environ.get('PNP_DNCNN_WINOGRAD') == '3') else 'f32',
+            'data': 'synthetic',
             'config': {'workload': f'pnp_svrg (true SVRG direction, T2={T2}, mb={MB}) on {H}x{W} CSMRI, '
                                    f'{int(SAMPLE_PROB * 100)}% mask, '
                                    + (f'DnCNN-17 prox ({wdesc})' if a.workload == 'dncnn' else 'TV (Haar BayesShrink) prox'),

@@ -164,7 +164,9 @@ int pnp_dncnn_plan_destroy(pnp_dncnn_plan* plan);
 int pnp_dncnn_set_affine(pnp_dncnn_plan* plan, const float* b_first, float b_last, float negative_slope);
 /* Conv kernel choice for the 64->64 layers: 1 = Winograd F(2,3) along x (default; fp32, executes 2/3 of the
  * multiply-adds), 0 = direct implicit GEMM (bit-for-bit an fmaf chain), 2 = Winograd with two workgroups per CU
- * (4-row tiles, per-phase weight re-fetch; same throughput, kept as a documented experiment; needs H % 4 == 0).  Default comes from the environment
+ * (4-row tiles, per-phase weight re-fetch; same throughput, kept as a documented experiment; needs H % 4 == 0),
+ * 3 = OPT-IN split-fp16 layers (every fp32 operand as two fp16 terms, three fp16 MFMAs per product, fp32
+ * accumulation: fp32-class accuracy at about half the time, but not the reference's arithmetic).  Default comes from the environment
  * variable PNP_DNCNN_WINOGRAD (unset = 1) at plan creation.                                       */
 int pnp_dncnn_set_winograd(pnp_dncnn_plan* plan, int enable);
 /* raw network: r = net(x), x and r [batch][H][W] fp32 (the predicted noise residual)          */

@@ -913,12 +913,12 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
     float *src = p->act0, *dst = p->act1;
     const bool prof = p->profile && p->ev_used + 2 <= p->ev.size();
-    if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
     if (p->use_wino == 3) {                                     // opt-in split-fp16 layers (dncnn_f16x3.hip)
         int rc = f16x3_to_a16(src, dst, H, W, B, s);
         if (rc != PNP_OK) return rc;
         float* t = src; src = dst; dst = t;
     }
+    if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
     for (int l = 0; l < p->n_mid; ++l) {
         if (p->use_wino == 3) {
             const int rc = f16x3_layer(src, dst, (const unsigned char*)p->wpack16 + f16x3_weight_bytes(1) * (size_t)l,

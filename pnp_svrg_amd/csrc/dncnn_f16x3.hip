@@ -34,11 +34,19 @@ constexpr int NW = 2 * 9 * 2;                                  // weight fragmen
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
 }  // namespace f16x3
 
-__device__ __forceinline__ void mfma_h(f32x4& acc, h8 w_agpr, h8 b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_agpr), "v"(b));
+// One pixel block x one tap: hi += wh*xh ; lo += wh*xl ; lo += wl*xh  (hand-issued: weights come from AGPRs, the
+// first tap of a tile uses the constant-zero accumulator form so the accumulators are never cleared).
+__device__ __forceinline__ void mfma3(f32x4& hi, f32x4& lo, h8 wh_agpr, h8 wl_agpr, h8 xh, h8 xl) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %2, %5, %1\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %3, %4, %1"
+                 : "+v"(hi), "+v"(lo) : "a"(wh_agpr), "a"(wl_agpr), "v"(xh), "v"(xl));
 }
-__device__ __forceinline__ void mfma_h_first(f32x4& acc, h8 w_agpr, h8 b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w_agpr), "v"(b));
+__device__ __forceinline__ void mfma3_first(f32x4& hi, f32x4& lo, h8 wh_agpr, h8 wl_agpr, h8 xh, h8 xl) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %4, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %2, %5, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %3, %4, %1"
+                 : "=&v"(hi), "=&v"(lo) : "a"(wh_agpr), "a"(wl_agpr), "v"(xh), "v"(xl));
 }
 
 // fp32 NCHW [B][64][H][W]  ->  A16 (see header).  One thread per (pixel, channel group).
@@ -142,12 +150,15 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
                 fl = *reinterpret_cast<const h8*>(cur + imm + GH * ROWS * PCR * 16);
             };
             constexpr int NS = ROWS * 6;                        // 60 fragment pairs per half
-            h8 fh[2], fl[2];
-            frag(0, fh[0], fl[0]);
+            constexpr int AHEAD = 2;                            // LDS reads run two fragment pairs ahead of their MFMAs
+            h8 fh[AHEAD + 1], fl[AHEAD + 1];
+#pragma unroll
+            for (int s = 0; s < AHEAD; ++s) frag(s, fh[s], fl[s]);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                if (s + 1 < NS) frag(s + 1, fh[(s + 1) & 1], fl[(s + 1) & 1]);
-                if (s % 5 == 0 && s / 5 < PPW) dma(s / 5, nsrc0, nedge, nvalid, nbuf);
+                if (s + AHEAD < NS) frag(s + AHEAD, fh[(s + AHEAD) % (AHEAD + 1)], fl[(s + AHEAD) % (AHEAD + 1)]);
+                // the next half's DMA goes out early: a half lasts only ~7k cycles, a late piece would be waited for
+                if (s % 2 == 0 && s / 2 < PPW) dma(s / 2, nsrc0, nedge, nvalid, nbuf);
                 const int rho = s / 6, xh = (s / 3) % 2, dx = s % 3;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
@@ -155,14 +166,8 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
                     if (r >= 0 && r < TR) {
                         const int pb = 2 * r + xh, tap = dy * 3 + dx;
                         const h8 wh = wreg[(half * 9 + tap) * 2 + 0], wl = wreg[(half * 9 + tap) * 2 + 1];
-                        if (half == 0 && tap == 0) {
-                            mfma_h_first(ah[pb], wh, fh[s & 1]);
-                            mfma_h_first(al[pb], wh, fl[s & 1]);
-                        } else {
-                            mfma_h(ah[pb], wh, fh[s & 1]);
-                            mfma_h(al[pb], wh, fl[s & 1]);
-                        }
-                        mfma_h(al[pb], wl, fh[s & 1]);
+                        if (half == 0 && tap == 0) mfma3_first(ah[pb], al[pb], wh, wl, fh[s % (AHEAD + 1)], fl[s % (AHEAD + 1)]);
+                        else mfma3(ah[pb], al[pb], wh, wl, fh[s % (AHEAD + 1)], fl[s % (AHEAD + 1)]);
                     }
                 }
             }

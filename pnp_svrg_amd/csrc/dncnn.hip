@@ -27,6 +27,7 @@
 //     matrix pipe is the only busy resource by a wide margin.
 #include "common.h"
 #include "f16x3.h"
+#include "tilewalk.h"
 #include "reduce.h"
 #include <vector>
 #include <algorithm>
@@ -119,16 +120,17 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
         poff[i] = (cin * H + pry[i]) * W + pcx4[i];
     }
 
-    int tile = blockIdx.x;
+    const TileWalk tw_ = tile_walk(ntiles);
+    int tile = tw_.first;
     {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
-        dma_half(in, zeros, lds, H, W, b, (t2 / tiles_x) * TR, (t2 % tiles_x) * TC, 0, tid, tile < ntiles);
+        dma_half(in, zeros, lds, H, W, b, (t2 / tiles_x) * TR, (t2 % tiles_x) * TC, 0, tid, tile < tw_.limit);
     }
     __syncthreads();                                        // (drains the DMA: vmcnt(0) + barrier)
     unsigned long long t0 = 0, r0 = 0, acc_compute = 0, acc_barrier = 0, acc_epi = 0, tp = 0;
     if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < tw_.limit; tile += tw_.step) {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
         f32x4 acc[MT];
@@ -139,11 +141,11 @@ __global__ __launch_bounds__(256, 1) void k_mid(const float* __restrict__ in, fl
         for (int half = 0; half < 2; ++half) {
             // prefetch target: the other K-half of this tile, or the first K-half of the next tile
             float* nbuf = lds + (half ^ 1) * HALF_LDS;
-            const int nt = tile + gridDim.x;
+            const int nt = tile + tw_.step;
             const int nb = half == 0 ? b : nt / tiles_per_img;
             const int n2 = nt - nb * tiles_per_img;
             const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
-            const bool nvalid = half == 0 ? true : nt < ntiles;
+            const bool nvalid = half == 0 ? true : nt < tw_.limit;
             const float* nsrc0 = in + (((size_t)nb * C + (half ^ 1) * HALF_C) * H + nty0 - 1) * (size_t)W + ntx0 - 4;
 
             // keep the buffer base in a register of its own: every B-operand address is then base +
@@ -336,16 +338,17 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
         pdesc[i] = (unsigned)((cin * H + ry) * W + cx4) | (edge << 28);
     }
 
-    int tile = blockIdx.x;
+    const TileWalk tw_ = tile_walk(ntiles);
+    int tile = tw_.first;
     {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
-        dma_half(in, zeros, lds, H, W, b, (t2 / tiles_x) * TR, (t2 % tiles_x) * TC, 0, tid, tile < ntiles);
+        dma_half(in, zeros, lds, H, W, b, (t2 / tiles_x) * TR, (t2 % tiles_x) * TC, 0, tid, tile < tw_.limit);
     }
     __syncthreads();
     unsigned long long t0 = 0, r0 = 0, acc_compute = 0, acc_barrier = 0, acc_epi = 0, tp = 0;
     if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < tw_.limit; tile += tw_.step) {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
         f32x4 acc[TR][4];                                       // written first by mfma_wa_first (half 0, channel quad 0, dy 0)
@@ -353,11 +356,11 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             float* nbuf = lds + (half ^ 1) * HALF_LDS;
-            const int nt = tile + gridDim.x;
+            const int nt = tile + tw_.step;
             const int nb = half == 0 ? b : nt / tiles_per_img;
             const int n2 = nt - nb * tiles_per_img;
             const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
-            const bool nvalid = half == 0 ? true : nt < ntiles;
+            const bool nvalid = half == 0 ? true : nt < tw_.limit;
             const float* nsrc0 = in + (((size_t)nb * C + (half ^ 1) * HALF_C) * H + nty0 - 1) * (size_t)W + ntx0 - 4;
             const unsigned nedge = ((nty0 == 0 ? 1u : 0u) | (nty0 + TR == H ? 2u : 0u) | (ntx0 == 0 ? 4u : 0u) | (ntx0 + TC == W ? 8u : 0u)) << 28;
 
@@ -501,17 +504,18 @@ __global__ __launch_bounds__(256, 2) void k_mid_wino2(const float* __restrict__ 
                                          (__attribute__((address_space(3))) void*)(buf + pc * 256), 16, 0, 0);
     };
 
-    int tile = blockIdx.x;
+    const TileWalk tw_ = tile_walk(ntiles);
+    int tile = tw_.first;
     {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * W2_TR, tx0 = (t2 % tiles_x) * TC;
         const float* src0 = in + (((size_t)b * C) * H + ty0 - 1) * (size_t)W + tx0 - 4;
 #pragma unroll
-        for (int g = 0; g < W2_PPW; ++g) issue_piece(g, lds, src0, ty0, tx0, tile < ntiles);
+        for (int g = 0; g < W2_PPW; ++g) issue_piece(g, lds, src0, ty0, tx0, tile < tw_.limit);
     }
     __syncthreads();
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < tw_.limit; tile += tw_.step) {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * W2_TR, tx0 = (t2 % tiles_x) * TC;
         f32x4 acc[W2_TR][4];
@@ -523,11 +527,11 @@ __global__ __launch_bounds__(256, 2) void k_mid_wino2(const float* __restrict__ 
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             float* nbuf = lds + (half ^ 1) * W2_HALF_LDS;
-            const int nt = tile + gridDim.x;
+            const int nt = tile + tw_.step;
             const int nb = half == 0 ? b : nt / tiles_per_img;
             const int n2 = nt - nb * tiles_per_img;
             const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * W2_TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
-            const bool nvalid = half == 0 ? true : nt < ntiles;
+            const bool nvalid = half == 0 ? true : nt < tw_.limit;
             const float* nsrc0 = in + (((size_t)nb * C + (half ^ 1) * HALF_C) * H + nty0 - 1) * (size_t)W + ntx0 - 4;
 
             // this phase's transformed weights (96 x 256 B, L2-resident; the SIMD partner computes meanwhile)

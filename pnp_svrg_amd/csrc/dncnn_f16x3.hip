@@ -15,6 +15,7 @@
 // Tile 8 x 32 pixels per workgroup, 4 waves x 16 output channels, weights stationary in AGPRs (144), two K-halves of
 // 32 channels as LDS double buffer filled by LDS-DMA, direct (not Winograd: its input transform is inexact in fp16).
 #include "common.h"
+#include "tilewalk.h"
 
 namespace pnp {
 
@@ -115,29 +116,30 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
         return ((ty0 == 0 ? 1u : 0u) | (ty0 + TR == H ? 2u : 0u) | (tx0 == 0 ? 4u : 0u) | (tx0 + TC == W ? 8u : 0u)) << 28;
     };
 
-    int tile = blockIdx.x;
+    const TileWalk tw_ = tile_walk(ntiles);
+    int tile = tw_.first;
     {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
         const h8* s0 = tile_src(b, ty0, tx0, 0);
         const unsigned e = tile_edge(ty0, tx0);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma(i, s0, e, tile < ntiles, lds);
+        for (int i = 0; i < PPW; ++i) dma(i, s0, e, tile < tw_.limit, lds);
     }
     __syncthreads();
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < tw_.limit; tile += tw_.step) {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
         f32x4 ah[16], al[16];                                   // pixel block pb = 2 r + xh; first written by mfma_h_first
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             unsigned char* nbuf = lds + (half ^ 1) * HALF_BYTES;
-            const int nt = tile + gridDim.x;
+            const int nt = tile + tw_.step;
             const int nb = half == 0 ? b : nt / tiles_per_img;
             const int n2 = nt - nb * tiles_per_img;
             const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
-            const bool nvalid = half == 0 ? true : nt < ntiles;
+            const bool nvalid = half == 0 ? true : nt < tw_.limit;
             const h8* nsrc0 = tile_src(nb, nty0, ntx0, half ^ 1);
             const unsigned nedge = tile_edge(nty0, ntx0);
             const unsigned char* cur = lds + half * HALF_BYTES + lb;

@@ -32,7 +32,7 @@ def short(name):
 shutil.copy(os.path.join(OUT, 'bench_prof.json'), os.path.join(ROOT, 'profiles', tag + '.json'))
 shutil.copy(newest('prof_stats/**/*kernel_stats.csv'), os.path.join(ROOT, 'profiles', tag + '_kernel_stats.csv'))
 lines = ['# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline',
-         '# mean counter value per dispatch (KiB); ' + note]
+         '# mean RAW counter value per dispatch (KiB); gfx950: double FETCH_SIZE for 16 B/lane streaming reads (MI355X_MICROARCH.md); ' + note]
 conv = {}
 for ctr, d in (('FETCH_SIZE', 'prof_pmc1'), ('WRITE_SIZE', 'prof_pmc2')):
     agg = {}
@@ -57,8 +57,11 @@ if len(conv) == 2:
     B = bench['config']['batch_per_gpu']
     tj = os.path.join(ROOT, 'profiles', 'traffic.json')
     t = json.load(open(tj)) if os.path.exists(tj) else {}
-    t[f'k_mid_B{B}'] = (conv['FETCH_SIZE'] + conv['WRITE_SIZE']) * 1024.0
-    t['note'] = f'raw FETCH_SIZE+WRITE_SIZE (KiB*1024) per conv launch at B={B}, separate --pmc passes; see profiles/{tag}_pmc_summary.txt'
+    # MI355X_MICROARCH.md, HBM section: the counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of
+    # wide (16 B/lane) streaming reads -- the conv kernel's LDS-DMA is that case -- so it is doubled; WRITE_SIZE is exact
+    t[f'k_mid_B{B}'] = (2.0 * conv['FETCH_SIZE'] + conv['WRITE_SIZE']) * 1024.0
+    t['note'] = (f'(2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per conv launch at B={B} (gfx950 correction of the guide: FETCH_SIZE '
+                 f'counts 64 B per 128-B request), separate --pmc passes; see profiles/{tag}_pmc_summary.txt')
     json.dump(t, open(tj, 'w'))
 print('\n'.join(lines[:3]), '...')
 print(open(os.path.join(ROOT, 'profiles', tag + '_kernel_stats.csv')).read()[:600])

@@ -211,9 +211,16 @@ def main():
         ach = alg / (dt / a.steps) / 1e9
         kern = ('whole inner iteration (k_draw_mb + k_rows_fwd + k_cols + ' +
                 ('k_rows_inv_prox: step, noise estimate, prox and error fused)' if a.fused_tv else 'k_rows_inv + k_prox_tv)'))
+        traffic = None
+        tj = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tj) and not a.fused_tv:
+            try:
+                traffic = json.load(open(tj)).get(f'tv_step_B{B}')     # PMC bytes of one whole step (all five kernels)
+            except Exception:
+                traffic = None
         roofline = {'bound': 'hbm', 'kernel': kern,
                     'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                    'traffic': None, 'bytes_per_step': alg}
+                    'traffic': traffic, 'bytes_per_step': alg}
 
     # final gather of the results (the only collective on this path; outside the timed region)
     trace = eng.psnr_trace()

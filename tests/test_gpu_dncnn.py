@@ -176,6 +176,12 @@ def test_split_fp16_conv_mode(W15, io):
     r3 = ops.DncnnPlan(W15, 40, 96, 3, winograd=3).forward(dev(xb)).cpu().numpy()
     for i in range(3):
         assert np.abs(r3[i] - od.dncnn_forward(W15, xb[i])).max() <= 2e-5
+    # a grid of several tiles per CU (the persistent walk, XCD-aware order): 4 different 256 x 256 images
+    x4 = rng.random((4, 256, 256)).astype(np.float32)
+    x4[0] = io['net256_in']
+    r3 = ops.DncnnPlan(W15, 256, 256, 4, winograd=3).forward(dev(x4)).cpu().numpy()
+    r0 = ops.DncnnPlan(W15, 256, 256, 4, winograd=0).forward(dev(x4)).cpu().numpy()
+    assert np.abs(r3[0] - io['net256_out']).max() <= 2e-5 and np.abs(r3 - r0).max() <= 2e-5
     z = dev(io['net64_in'][None] * 0.8 + 0.1, torch.float64)
     a, _ = ops.DncnnPlan(W15, 64, 64, 1, winograd=3).denoise(z, 15.0)
     b, _ = ops.DncnnPlan(W15, 64, 64, 1, winograd=0).denoise(z, 15.0)

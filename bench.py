@@ -42,7 +42,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='independent reconstructions per GPU')
+    ap.add_argument('--batch', type=int, default=120,
+                    help='independent reconstructions per GPU (default 120 = one Set12 x 10 sampling-ratio sweep, BASELINE config 5)')
     ap.add_argument('--workload', default='dncnn', choices=['dncnn', 'tv'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],

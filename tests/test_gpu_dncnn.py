@@ -102,7 +102,7 @@ def test_simplecnn_family(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('winograd', [True, False])
+@pytest.mark.parametrize('winograd', [True, False, 3])
 def test_mmo_denoiser_vs_reference(winograd):
     """SURVEY 8(f) n3: MMODenoiser (20-layer bias / LeakyReLU(0.01) / skip net, transposed input, both clamps;
     reference denoisers/MMODenoise.py:18-40,73-128) through the MFMA conv stack vs the reference's own classes
@@ -116,7 +116,7 @@ def test_mmo_denoiser_vs_reference(winograd):
         sd['module.' + n + '.weight'] = torch.from_numpy(g[f'conv{i}.weight'])
         sd['module.' + n + '.bias'] = torch.from_numpy(g[f'conv{i}.bias'])
     old = os.environ.get('PNP_DNCNN_WINOGRAD')
-    os.environ['PNP_DNCNN_WINOGRAD'] = '1' if winograd else '0'
+    os.environ['PNP_DNCNN_WINOGRAD'] = '3' if winograd == 3 else ('1' if winograd else '0')   # 3 = split-fp16 layers
     try:
         den = MMODenoiser(model=sd, channels=1)
         for name in ('sq', 'rect'):

@@ -84,6 +84,17 @@ def test_winograd_vs_direct(W15, io):
     assert not np.array_equal(rw, rd)                          # really two different kernels
     assert np.abs(rw - rd).max() <= 1e-5
     assert np.abs(rw - io['net256_out']).max() <= 2e-5 and np.abs(rd - io['net256_out']).max() <= 2e-5
+    # several tiles per persistent workgroup in the XCD-aware order (tilewalk.h), and a count that does not divide
+    # (plain walk): every image of a batch must equal its single-image result, for all conv kernels
+    rng = np.random.default_rng(5)
+    for B in (6, 5):
+        xb = rng.random((B, 256, 256)).astype(np.float32)
+        xb[B - 1] = io['net256_in']
+        for mode in (1, 0, 2):
+            rb = ops.DncnnPlan(W15, 256, 256, B, winograd=mode).forward(dev(xb)).cpu().numpy()
+            one = ops.DncnnPlan(W15, 256, 256, 1, winograd=mode).forward(dev(xb[1:2])).cpu().numpy()[0]
+            assert np.array_equal(rb[1], one), (B, mode)
+            assert np.abs(rb[B - 1] - io['net256_out']).max() <= 2e-5
 
 
 @pytest.mark.parametrize('name', ['SimpleCNN', 'RealSN_SimpleCNN'])

@@ -2,11 +2,11 @@
 //
 // The default conv kernels (dncnn.hip) multiply in fp32 on v_mfma_f32_16x16x4_f32, whose rate is the vector rate
 // (157 TFLOP/s).  The fp16-input MFMA runs 16x faster.  This kernel keeps fp32 accuracy by SPLITTING every fp32
-// operand into two fp16 terms,  x = xh + xl  (xh = fp16(x), xl = fp16(x - xh); 22 significant bits), and evaluating
-// x w = xh wh + xh wl + xl wh  -- three fp16 MFMAs into ONE fp32 accumulator, dropping only the 2^-22 cross term.
-// The low terms reach into fp16's subnormals (|xl| <= 2^-12 |x|); the MFMA does not flush them (measured: scaling the
-// low parts by 2^11 into a second accumulator set changes the deviation from the reference network by < 1e-7), so
-// the absolute error of an operand is <= 2^-25 and the relative one 2^-22 above |x| ~ 1e-3.
+// operand into two fp16 terms,  x = xh + 2^-11 xl  (xh = fp16(x), xl = fp16(2^11 (x - xh)); 22 significant bits),
+// and evaluating  x w = xh wh + 2^-11 (xh wl + xl wh)  -- three fp16 MFMAs, dropping only the 2^-22 term -- with
+// fp32 accumulation in two accumulator sets.  The 2^11 scaling keeps the low parts out of fp16's subnormals: the MFMA
+// does not flush them, and at O(1) activations one accumulator with unscaled low parts measures the same error and
+// is 5 % faster, but at activations of 1e-3 its error is 30x the fp32 kernels' (test_conv_kernels_against_float64).
 // Relative error per product <= ~3 * 2^-22, i.e. the size of fp32's own rounding over a 576-term dot product.
 // It is NOT the arithmetic of the reference (plain fp32), so it is never the default and bench.py's headline never
 // uses it; `pnp_dncnn_set_winograd(plan, 3)` selects it, tests bound its deviation from the fp32 kernels.
@@ -34,21 +34,22 @@ constexpr int PIECES = (RECS + 63) / 64;                       // 43 wave-pieces
 constexpr int PPW = (PIECES + 3) / 4;                          // 11 per wave
 constexpr int HALF_BYTES = PIECES * 64 * 16;                   // 44 032
 constexpr int NW = 2 * 9 * 2;                                  // weight fragments per wave: half x tap x part
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
 }  // namespace f16x3
 
-// One pixel block x one tap: acc += wh*xl + wl*xh + wh*xh, small terms first (hand-issued: weights come from AGPRs,
-// the first tap of a tile uses the constant-zero accumulator form so the accumulators are never cleared).
-__device__ __forceinline__ void mfma3(f32x4& acc, h8 wh_agpr, h8 wl_agpr, h8 xh, h8 xl) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %4, %0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0"
-                 : "+v"(acc) : "a"(wh_agpr), "a"(wl_agpr), "v"(xh), "v"(xl));
+// One pixel block x one tap: hi += wh*xh ; lo += wh*xl ; lo += wl*xh  (hand-issued: weights come from AGPRs, the
+// first tap of a tile uses the constant-zero accumulator form so the accumulators are never cleared).
+__device__ __forceinline__ void mfma3(f32x4& hi, f32x4& lo, h8 wh_agpr, h8 wl_agpr, h8 xh, h8 xl) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %4, %0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %2, %5, %1\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %3, %4, %1"
+                 : "+v"(hi), "+v"(lo) : "a"(wh_agpr), "a"(wl_agpr), "v"(xh), "v"(xl));
 }
-__device__ __forceinline__ void mfma3_first(f32x4& acc, h8 wh_agpr, h8 wl_agpr, h8 xh, h8 xl) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %4, 0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0"
-                 : "=&v"(acc) : "a"(wh_agpr), "a"(wl_agpr), "v"(xh), "v"(xl));
+__device__ __forceinline__ void mfma3_first(f32x4& hi, f32x4& lo, h8 wh_agpr, h8 wl_agpr, h8 xh, h8 xl) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %4, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %2, %5, 0\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %3, %4, %1"
+                 : "=&v"(hi), "=&v"(lo) : "a"(wh_agpr), "a"(wl_agpr), "v"(xh), "v"(xl));
 }
 
 // fp32 NCHW [B][64][H][W]  ->  A16 (see header).  One thread per (pixel, channel group).
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void k_to_a16(const float* __restrict__ in, h8
         const float v = in[((size_t)b * f16x3::C + grp * 8 + j) * HW + p];
         const _Float16 h = (_Float16)v;
         hi[j] = h;
-        lo[j] = (_Float16)(v - (float)h);
+        lo[j] = (_Float16)((v - (float)h) * f16x3::LO_SCALE);
     }
     out[((size_t)(b * 2 + 0) * 8 + grp) * HW + p] = hi;
     out[((size_t)(b * 2 + 1) * 8 + grp) * HW + p] = lo;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
     for (; tile < tw_.limit; tile += tw_.step) {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
-        f32x4 acc[16];                                          // pixel block pb = 2 r + xh; first written by mfma3_first
+        f32x4 ah[16], al[16];                                   // pixel block pb = 2 r + xh; first written by mfma_h_first
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             unsigned char* nbuf = lds + (half ^ 1) * HALF_BYTES;
@@ -169,15 +170,15 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
                     if (r >= 0 && r < TR) {
                         const int pb = 2 * r + xh, tap = dy * 3 + dx;
                         const h8 wh = wreg[(half * 9 + tap) * 2 + 0], wl = wreg[(half * 9 + tap) * 2 + 1];
-                        if (half == 0 && tap == 0) mfma3_first(acc[pb], wh, wl, fh[s % (AHEAD + 1)], fl[s % (AHEAD + 1)]);
-                        else mfma3(acc[pb], wh, wl, fh[s % (AHEAD + 1)], fl[s % (AHEAD + 1)]);
+                        if (half == 0 && tap == 0) mfma3_first(ah[pb], al[pb], wh, wl, fh[s % (AHEAD + 1)], fl[s % (AHEAD + 1)]);
+                        else mfma3(ah[pb], al[pb], wh, wl, fh[s % (AHEAD + 1)], fl[s % (AHEAD + 1)]);
                     }
                 }
             }
             __syncthreads();                                    // next half landed (vmcnt(0)) + everyone done reading
         }
 
-        // epilogue: bias, activation, then split again (A16) or plain fp32 (layer before k_last)
+        // epilogue: v = hi + 2^-11 lo + bias, activation, then split again (A16) or plain fp32 (layer before k_last)
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");       // MFMA write -> VALU read distance (hand-issued MFMAs)
 #pragma unroll
         for (int pb = 0; pb < 16; ++pb) {
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float t = acc[pb][q] + bv[q];
+                float t = (ah[pb][q] + al[pb][q] * LO_INV) + bv[q];
                 t = t > 0.f ? t : (LEAKY ? slope * t : 0.f);
                 v[q] = t;
             }
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
                 for (int q = 0; q < 4; ++q) {
                     const _Float16 h = (_Float16)v[q];
                     hi[q] = h;
-                    lo[q] = (_Float16)(v[q] - (float)h);
+                    lo[q] = (_Float16)((v[q] - (float)h) * LO_SCALE);
                 }
                 // couts 16 wv + 4 (lane>>4) + q -> group 2 wv + (lane >> 5), half-record (lane >> 4) & 1
                 h4* o = (h4*)outv;
@@ -230,7 +231,7 @@ void f16x3_pack_weights(const float* w_mid, int n_mid, void* out_h8) {
                             const float v = w_mid[(((size_t)l * C + cout) * C + cin) * 9 + tap];
                             const _Float16 h = (_Float16)v;
                             hi[j] = h;
-                            lo[j] = (_Float16)(v - (float)h);
+                            lo[j] = (_Float16)((v - (float)h) * LO_SCALE);
                         }
                         const size_t base = (((size_t)l * 4 + wv) * NW + (half * 9 + tap) * 2) * 64 + lane;
                         out[base] = hi;

@@ -197,3 +197,32 @@ def test_split_fp16_conv_mode(W15, io):
     a, _ = ops.DncnnPlan(W15, 64, 64, 1, winograd=3).denoise(z, 15.0)
     b, _ = ops.DncnnPlan(W15, 64, 64, 1, winograd=0).denoise(z, 15.0)
     assert (a - b).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize('scale', [1.0, 1e-3, 50.0])
+def test_conv_kernels_against_float64(scale):
+    """Error of each conv kernel against a float64 evaluation of the same 3-layer net (1->64, 64->64 + bias + ReLU,
+    64->1; random weights), at activation scales from 1e-3 to 50: the opt-in split-fp16 kernel stays within 2x the
+    error of the plain fp32 kernels (it is an fp32-class evaluation, not a reduced-precision one), fp16 range
+    permitting (|activation| < 65504)."""
+    import torch.nn.functional as F
+    from pnp_svrg_amd import ops
+    rng = np.random.default_rng(11)
+    n = 64
+    w = {'n_layers': np.int64(3),
+         'conv0.weight': (rng.standard_normal((64, 1, 3, 3)) * scale).astype(np.float32),
+         'conv1.weight': (rng.standard_normal((64, 64, 3, 3)) / 24.0).astype(np.float32),
+         'conv1.bias': (rng.standard_normal(64) * 0.1 * scale).astype(np.float32),
+         'conv2.weight': (rng.standard_normal((1, 64, 3, 3)) / 24.0).astype(np.float32)}
+    x = rng.random((2, n, n)).astype(np.float32)
+    t = torch.from_numpy(x).double()[:, None]
+    t = F.relu(F.conv2d(t, torch.from_numpy(w['conv0.weight']).double(), padding=1))
+    t = F.relu(F.conv2d(t, torch.from_numpy(w['conv1.weight']).double(), torch.from_numpy(w['conv1.bias']).double(), padding=1))
+    ref = F.conv2d(t, torch.from_numpy(w['conv2.weight']).double(), padding=1)[:, 0].numpy()
+    err = {}
+    for mode in (0, 1, 3):
+        r = ops.DncnnPlan(w, n, n, 2, winograd=mode).forward(dev(x)).cpu().numpy().astype(np.float64)
+        err[mode] = np.abs(r - ref).max() / np.abs(ref).max()
+    print(f'scale {scale}: relative max error vs float64 -- fp32 direct {err[0]:.2e}, fp32 Winograd {err[1]:.2e}, split-fp16 {err[3]:.2e}')
+    assert err[0] < 2e-6 and err[1] < 2e-6
+    assert err[3] < 2 * max(err[0], err[1]) + 1e-7

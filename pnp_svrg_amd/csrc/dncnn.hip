@@ -625,7 +625,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T* __restrict__ mm,
                                                const float* __restrict__ w, const float* __restrict__ bfirst,
                                                float* __restrict__ out, int H, int W, double srange, double sshift,
-                                               int clamp01, float slope) {
+                                               int clamp01, float slope, int a16) {
     __shared__ float ws[C * 9];
     __shared__ float bs[C];
     for (int i = threadIdx.x; i < C * 9; i += 256) ws[i] = w[i];
@@ -653,6 +653,32 @@ __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T*
             q = (float)u;
         }
         v[t] = q;
+    }
+    if (a16) {
+        // split-fp16 pipeline (dncnn_f16x3.hip): emit the "A16" records directly -- per channel group of 8 one 16-byte
+        // record of high parts fp16(a) and one of low parts fp16(2^11 (a - hi))
+        typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+        h8v* o16 = reinterpret_cast<h8v*>(out);
+        const size_t HW = (size_t)H * W;
+#pragma unroll 1
+        for (int g = 0; g < C / 8; ++g) {
+            h8v hi8, lo8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 8 * g + j;
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) a = fmaf(ws[c * 9 + t], v[t], a);
+                a += bs[c];
+                a = a > 0.f ? a : slope * a + 0.f;
+                const _Float16 h = (_Float16)a;
+                hi8[j] = h;
+                lo8[j] = (_Float16)((a - (float)h) * 2048.f);
+            }
+            o16[((size_t)(b * 2 + 0) * 8 + g) * HW + p] = hi8;
+            o16[((size_t)(b * 2 + 1) * 8 + g) * HW + p] = lo8;
+        }
+        return;
     }
 #pragma unroll 4
     for (int c = 0; c < C; ++c) {
@@ -911,17 +937,13 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
         sshift = (1.0 - srange) / 2.0;
     }
     dim3 pg(HW / 256, B);
-    k_first<T><<<pg, 256, 0, s>>>(z_in, mm, p->w_first, p->b_first, p->act0, H, W, srange, sshift, mmo ? 1 : 0, p->slope);
+    k_first<T><<<pg, 256, 0, s>>>(z_in, mm, p->w_first, p->b_first, p->act0, H, W, srange, sshift, mmo ? 1 : 0, p->slope,
+                                  p->use_wino == 3 ? 1 : 0);
     PNP_CHECK_LAUNCH();
     const int ntiles = B * (H / TR) * (W / TC);
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
     float *src = p->act0, *dst = p->act1;
     const bool prof = p->profile && p->ev_used + 2 <= p->ev.size();
-    if (p->use_wino == 3) {                                     // opt-in split-fp16 layers (dncnn_f16x3.hip)
-        int rc = f16x3_to_a16(src, dst, H, W, B, s);
-        if (rc != PNP_OK) return rc;
-        float* t = src; src = dst; dst = t;
-    }
     if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
     for (int l = 0; l < p->n_mid; ++l) {
         if (p->use_wino == 3) {

@@ -11,7 +11,7 @@
 // It is NOT the arithmetic of the reference (plain fp32), so it is never the default and bench.py's headline never
 // uses it; `pnp_dncnn_set_winograd(plan, 3)` selects it, tests bound its deviation from the fp32 kernels.
 //
-// Activation format between split layers ("A16"): per image 2 parts (hi, lo) x 8 channel groups planes of [H][W]
+// Activation format between split layers ("A16", produced by k_first in this mode and by every split layer): per image 2 parts (hi, lo) x 8 channel groups planes of [H][W]
 // 16-byte records holding 8 fp16 channels -- exactly the B fragment of one lane of v_mfma_f32_16x16x32_f16
 // (k = 8 (lane >> 4) + j), so a lane's operand is ONE ds_read_b128 with an immediate offset; same bytes as fp32 NCHW.
 // Tile 8 x 32 pixels per workgroup, 4 waves x 16 output channels, weights stationary in AGPRs (144), two K-halves of
@@ -50,22 +50,6 @@ __device__ __forceinline__ void mfma3_first(f32x4& hi, f32x4& lo, h8 wh_agpr, h8
                  "v_mfma_f32_16x16x32_f16 %1, %2, %5, 0\n\t"
                  "v_mfma_f32_16x16x32_f16 %1, %3, %4, %1"
                  : "=&v"(hi), "=&v"(lo) : "a"(wh_agpr), "a"(wl_agpr), "v"(xh), "v"(xl));
-}
-
-// fp32 NCHW [B][64][H][W]  ->  A16 (see header).  One thread per (pixel, channel group).
-__global__ __launch_bounds__(256) void k_to_a16(const float* __restrict__ in, h8* __restrict__ out, int HW) {
-    const int b = blockIdx.z, grp = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    h8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = in[((size_t)b * f16x3::C + grp * 8 + j) * HW + p];
-        const _Float16 h = (_Float16)v;
-        hi[j] = h;
-        lo[j] = (_Float16)((v - (float)h) * f16x3::LO_SCALE);
-    }
-    out[((size_t)(b * 2 + 0) * 8 + grp) * HW + p] = hi;
-    out[((size_t)(b * 2 + 1) * 8 + grp) * HW + p] = lo;
 }
 
 // OUT_F32: write fp32 NCHW (the layer feeding k_last) instead of A16.
@@ -270,10 +254,4 @@ int f16x3_layer(const void* in_a16, void* out, const void* wpack_layer, const fl
     return PNP_OK;
 }
 
-int f16x3_to_a16(const float* in, void* out_a16, int H, int W, int batch, hipStream_t s) {
-    const int HW = H * W;
-    k_to_a16<<<dim3((HW + 255) / 256, 8, batch), 256, 0, s>>>(in, (h8*)out_a16, HW);
-    PNP_CHECK_LAUNCH();
-    return PNP_OK;
-}
 }  // namespace pnp

@@ -56,8 +56,11 @@ __device__ __forceinline__ void mfma3_first(f32x4& hi, f32x4& lo, h8 wh_agpr, h8
 template <bool OUT_F32, bool LEAKY>
 __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in, void* __restrict__ outv,
                                                       const h8* __restrict__ wpack, const float* __restrict__ bias,
-                                                      const h8* __restrict__ zeros, int H, int W, int ntiles, float slope) {
+                                                      const h8* __restrict__ zeros, int H, int W, int ntiles, float slope,
+                                                      unsigned long long* __restrict__ stamps) {
     using namespace f16x3;
+    // diagnostic (pnp_dncnn_debug_clock): shader cycles and 100 MHz reference ticks of the whole workgroup
+    const unsigned long long st_c = __builtin_amdgcn_s_memtime(), st_r = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
@@ -194,6 +197,10 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
             }
         }
     }
+    if (stamps != nullptr && tid == 0) {
+        stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c;
+        stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
+    }
 }
 
 }  // namespace pnp
@@ -227,7 +234,7 @@ size_t f16x3_weight_bytes(int n_mid) { return (size_t)n_mid * 4 * f16x3::NW * 64
 
 // One 64->64 layer.  in_a16 / out: A16 buffers (out fp32 NCHW when out_f32).  zeros: >= 16 zero bytes.
 int f16x3_layer(const void* in_a16, void* out, const void* wpack_layer, const float* bias, const void* zeros,
-                               int H, int W, int batch, int num_cu, int out_f32, float slope, hipStream_t s) {
+                int H, int W, int batch, int num_cu, int out_f32, float slope, hipStream_t s, unsigned long long* stamps) {
     using namespace f16x3;
     const int ntiles = batch * (H / TR) * (W / TC);
     const int grid = ntiles < num_cu ? ntiles : num_cu;
@@ -244,11 +251,11 @@ int f16x3_layer(const void* in_a16, void* out, const void* wpack_layer, const fl
     const h8* wp = (const h8*)wpack_layer;
     const h8* z = (const h8*)zeros;
     if (slope != 0.f) {
-        if (out_f32) k_mid_f16x3<true, true><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, slope);
-        else k_mid_f16x3<false, true><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, slope);
+        if (out_f32) k_mid_f16x3<true, true><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, slope, stamps);
+        else k_mid_f16x3<false, true><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, slope, stamps);
     } else {
-        if (out_f32) k_mid_f16x3<true, false><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, 0.f);
-        else k_mid_f16x3<false, false><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, 0.f);
+        if (out_f32) k_mid_f16x3<true, false><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, 0.f, stamps);
+        else k_mid_f16x3<false, false><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, 0.f, stamps);
     }
     PNP_CHECK_LAUNCH();
     return PNP_OK;

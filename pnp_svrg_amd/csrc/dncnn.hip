@@ -1044,13 +1044,18 @@ extern "C" int pnp_dncnn_debug_clock(pnp_dncnn_plan* p, int reps, double* cycles
                                        i == reps - 1 ? d : nullptr);
             if (rc != PNP_OK) { (void)hipFree(d); return rc; }
         }
-        std::vector<unsigned long long> h2((size_t)grid * 2);
+        std::vector<unsigned long long> h2((size_t)grid * 5);
         hipError_t e2 = hipMemcpyAsync(h2.data(), d, h2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
         (void)hipFree(d);
         PNP_CHECK_HIP(e2);
         std::vector<double> c2(grid), r2(grid);
-        for (int i = 0; i < grid; ++i) { c2[i] = (double)h2[2 * i]; r2[i] = (double)h2[2 * i + 1]; }
+        for (int i = 0; i < grid; ++i) { c2[i] = (double)h2[5 * i]; r2[i] = (double)h2[5 * i + 1]; }
+        if (getenv("PNP_DEBUG_STAMPS")) {
+            double a = 0, b = 0, ep = 0;
+            for (int i = 0; i < grid; ++i) { a += h2[5 * i + 2]; b += h2[5 * i + 3]; ep += h2[5 * i + 4]; }
+            fprintf(stderr, "[k_mid_f16x3 stamps] mean cycles per WG: compute %.0f  barrier %.0f  epilogue %.0f\n", a / grid, b / grid, ep / grid);
+        }
         std::sort(c2.begin(), c2.end());
         std::sort(r2.begin(), r2.end());
         *cycles = c2[grid / 2];

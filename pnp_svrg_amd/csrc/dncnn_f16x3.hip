@@ -53,7 +53,7 @@ __device__ __forceinline__ void mfma3_first(f32x4& hi, f32x4& lo, h8 wh_agpr, h8
 }
 
 // OUT_F32: write fp32 NCHW (the layer feeding k_last) instead of A16.
-template <bool OUT_F32, bool LEAKY>
+template <bool OUT_F32, bool LEAKY, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in, void* __restrict__ outv,
                                                       const h8* __restrict__ wpack, const float* __restrict__ bias,
                                                       const h8* __restrict__ zeros, int H, int W, int ntiles, float slope,
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
     }
     __syncthreads();
 
+    unsigned long long acc_compute = 0, acc_barrier = 0, acc_epi = 0, tp = 0;
     for (; tile < tw_.limit; tile += tw_.step) {
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
@@ -132,37 +133,64 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
             const h8* nsrc0 = tile_src(nb, nty0, ntx0, half ^ 1);
             const unsigned nedge = tile_edge(nty0, ntx0);
             const unsigned char* cur = lds + half * HALF_BYTES + lb;
+            if (STAMP) tp = __builtin_amdgcn_s_memtime();
 
-            // fragment (rho, xh, dx): halo row rho, 16-pixel half xh, horizontal tap dx -> hi and lo records
-            auto frag = [&](int s, h8& fh, h8& fl) {
-                const int rho = s / 6, xh = (s / 3) % 2, dx = s % 3;
-                const int imm = ((rho * PCR) + 16 * xh + dx) * 16;
-                fh = *reinterpret_cast<const h8*>(cur + imm);
-                fl = *reinterpret_cast<const h8*>(cur + imm + GH * ROWS * PCR * 16);
-            };
+            // fragment s = (rho, xh, dx): halo row rho, 16-pixel half xh, horizontal tap dx -> hi and lo records, as two
+            // hand-issued ds_read_b128 with immediate offsets off one base register.  The reads run AHEAD fragments
+            // ahead of their MFMAs and are retired by a COUNTED wait (LDS returns in order): left to hipcc every use
+            // waits lgkmcnt(0), i.e. also for the reads just issued for the fragments behind it.  The 60 steps are
+            // spelled out by macro so that every offset is a constant expression (an asm immediate).
+            const unsigned cur_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + half * HALF_BYTES + lb;
             constexpr int NS = ROWS * 6;                        // 60 fragment pairs per half
             constexpr int AHEAD = 2;                            // LDS reads run two fragment pairs ahead of their MFMAs
             h8 fh[AHEAD + 1], fl[AHEAD + 1];
-#pragma unroll
-            for (int s = 0; s < AHEAD; ++s) frag(s, fh[s], fl[s]);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (s + AHEAD < NS) frag(s + AHEAD, fh[(s + AHEAD) % (AHEAD + 1)], fl[(s + AHEAD) % (AHEAD + 1)]);
-                // the next half's DMA goes out early: a half lasts only ~7k cycles, a late piece would be waited for
-                if (s % 2 == 0 && s / 2 < PPW) dma(s / 2, nsrc0, nedge, nvalid, nbuf);
-                const int rho = s / 6, xh = (s / 3) % 2, dx = s % 3;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int r = rho - dy;
-                    if (r >= 0 && r < TR) {
-                        const int pb = 2 * r + xh, tap = dy * 3 + dx;
-                        const h8 wh = wreg[(half * 9 + tap) * 2 + 0], wl = wreg[(half * 9 + tap) * 2 + 1];
-                        if (half == 0 && tap == 0) mfma3_first(ah[pb], al[pb], wh, wl, fh[s % (AHEAD + 1)], fl[s % (AHEAD + 1)]);
-                        else mfma3(ah[pb], al[pb], wh, wl, fh[s % (AHEAD + 1)], fl[s % (AHEAD + 1)]);
-                    }
-                }
-            }
+#define F16X3_LOAD(S_)                                                                                                        \
+    {                                                                                                                         \
+        constexpr int s_ = (S_), imm_ = (((s_ / 6) * PCR) + 16 * ((s_ / 3) % 2) + s_ % 3) * 16;                               \
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"                                        \
+                     : "=&v"(fh[s_ % (AHEAD + 1)]), "=&v"(fl[s_ % (AHEAD + 1)])                                               \
+                     : "v"(cur_addr), "n"(imm_), "n"(imm_ + GH * ROWS * PCR * 16) : "memory");                                \
+    }
+#define F16X3_STEP(S_)                                                                                                        \
+    {                                                                                                                         \
+        constexpr int s = (S_);                                                                                               \
+        if constexpr (s + AHEAD < NS) F16X3_LOAD(s + AHEAD)                                                                   \
+        {   /* fragment s has landed once at most the reads of the fragments issued after it are outstanding */               \
+            constexpr int behind = (NS - 1 - s) < AHEAD ? (NS - 1 - s) : AHEAD;                                               \
+            if constexpr (behind == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[s % 3]), "+v"(fl[s % 3]) :: "memory");   \
+            else if constexpr (behind == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[s % 3]), "+v"(fl[s % 3]) :: "memory"); \
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[s % 3]), "+v"(fl[s % 3]) :: "memory");                         \
+        }                                                                                                                     \
+        /* the next half's DMA goes out early: a half lasts only ~7k cycles, a late piece would be waited for */            \
+        if constexpr (s % 2 == 0 && s / 2 < PPW) dma(s / 2, nsrc0, nedge, nvalid, nbuf);                                      \
+        constexpr int rho = s / 6, xh = (s / 3) % 2, dx = s % 3;                                                              \
+        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) {                                                                    \
+            const int r = rho - dy;                                                                                           \
+            if (r >= 0 && r < TR) {                                                                                           \
+                const int pb = 2 * r + xh, tap = dy * 3 + dx;                                                                 \
+                const h8 wh = wreg[(half * 9 + tap) * 2 + 0], wl = wreg[(half * 9 + tap) * 2 + 1];                            \
+                if (half == 0 && tap == 0) mfma3_first(ah[pb], al[pb], wh, wl, fh[s % 3], fl[s % 3]);                         \
+                else mfma3(ah[pb], al[pb], wh, wl, fh[s % 3], fl[s % 3]);                                                     \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+            static_assert(AHEAD == 2 && NS == 60, "the step list below is written for 60 steps, two fragments ahead");
+            F16X3_LOAD(0) F16X3_LOAD(1)
+            F16X3_STEP(0) F16X3_STEP(1) F16X3_STEP(2) F16X3_STEP(3) F16X3_STEP(4) F16X3_STEP(5) 
+            F16X3_STEP(6) F16X3_STEP(7) F16X3_STEP(8) F16X3_STEP(9) F16X3_STEP(10) F16X3_STEP(11) 
+            F16X3_STEP(12) F16X3_STEP(13) F16X3_STEP(14) F16X3_STEP(15) F16X3_STEP(16) F16X3_STEP(17) 
+            F16X3_STEP(18) F16X3_STEP(19) F16X3_STEP(20) F16X3_STEP(21) F16X3_STEP(22) F16X3_STEP(23) 
+            F16X3_STEP(24) F16X3_STEP(25) F16X3_STEP(26) F16X3_STEP(27) F16X3_STEP(28) F16X3_STEP(29) 
+            F16X3_STEP(30) F16X3_STEP(31) F16X3_STEP(32) F16X3_STEP(33) F16X3_STEP(34) F16X3_STEP(35) 
+            F16X3_STEP(36) F16X3_STEP(37) F16X3_STEP(38) F16X3_STEP(39) F16X3_STEP(40) F16X3_STEP(41) 
+            F16X3_STEP(42) F16X3_STEP(43) F16X3_STEP(44) F16X3_STEP(45) F16X3_STEP(46) F16X3_STEP(47) 
+            F16X3_STEP(48) F16X3_STEP(49) F16X3_STEP(50) F16X3_STEP(51) F16X3_STEP(52) F16X3_STEP(53) 
+            F16X3_STEP(54) F16X3_STEP(55) F16X3_STEP(56) F16X3_STEP(57) F16X3_STEP(58) F16X3_STEP(59) 
+#undef F16X3_STEP
+#undef F16X3_LOAD
+            if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_compute += t - tp; tp = t; }
             __syncthreads();                                    // next half landed (vmcnt(0)) + everyone done reading
+            if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_barrier += t - tp; tp = t; }
         }
 
         // epilogue: v = hi + 2^-11 lo + bias, activation, then split again (A16) or plain fp32 (layer before k_last)
@@ -196,10 +224,14 @@ __global__ __launch_bounds__(256, 1) void k_mid_f16x3(const h8* __restrict__ in,
                 o[(rec + (size_t)8 * HW) * 2 + ((lane >> 4) & 1)] = lo;
             }
         }
+        if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_epi += t - tp; }
     }
     if (stamps != nullptr && tid == 0) {
-        stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c;
-        stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
+        stamps[5 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c;
+        stamps[5 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
+        stamps[5 * blockIdx.x + 2] = acc_compute;               // STAMP builds only: MFMA phases / barrier waits / epilogues
+        stamps[5 * blockIdx.x + 3] = acc_barrier;
+        stamps[5 * blockIdx.x + 4] = acc_epi;
     }
 }
 
@@ -245,6 +277,7 @@ int f16x3_layer(const void* in_a16, void* out, const void* wpack_layer, const fl
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_mid_f16x3<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_mid_f16x3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_mid_f16x3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_mid_f16x3<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         attr = true;
     }
     const h8* in = (const h8*)in_a16;
@@ -255,6 +288,7 @@ int f16x3_layer(const void* in_a16, void* out, const void* wpack_layer, const fl
         else k_mid_f16x3<false, true><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, slope, stamps);
     } else {
         if (out_f32) k_mid_f16x3<true, false><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, 0.f, stamps);
+        else if (stamps != nullptr) k_mid_f16x3<false, false, true><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, 0.f, stamps);
         else k_mid_f16x3<false, false><<<grid, 256, ldsb, s>>>(in, out, wp, bias, z, H, W, ntiles, 0.f, stamps);
     }
     PNP_CHECK_LAUNCH();

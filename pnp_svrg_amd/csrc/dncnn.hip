@@ -373,15 +373,17 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
             f32x2v d[2][5][2];
             const unsigned xb_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + 4u * (unsigned)xb_off;
             wino_lds_load(d[0], xb_addr);
-            wino_lds_wait(d[0]);
-            // B^T d runs ONE ROW AHEAD of the MFMAs that consume it (software pipeline): the two packed adds of row
-            // i+1 issue before the 4-12 MFMAs of row i, so no wait states are needed between a VALU write and the
-            // MFMA that reads it (the hazard recognizer does not see inside the asm; pk -> MFMA needs 2).
-            f32x2v vc01, vc23;
-            wino_bt(vc01, vc23, d[0][0][0], d[0][0][1]);
+            // All non-MFMA work of a group -- retire the group's LDS reads, issue the next group's, one DMA piece, the ten
+            // packed adds of B^T d for the group's five halo rows -- is issued as ONE block in front of the group's 48
+            // MFMAs.  On gfx950 every excursion from the MFMA stream to the vector ALU and back costs ~10 cycles on top
+            // of ~4.3 per instruction (tools/microbench/mfma_f32_valu.hip: one v_pk_add_f32 between two fp32 MFMAs takes
+            // them from 32.3 to 46.8 cycles), so the number of excursions counts, not only the instruction count.  It
+            // also puts >= 2 instructions between every transform and the MFMA that reads it (VALU -> MFMA wait
+            // states; the hazard recognizer does not see inside the asm).
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int c4 = g / 2, rb = g % 2;
+                wino_lds_wait(d[g & 1]);                        // issued a whole group ago (or just above for g = 0)
                 if (g + 1 < NG) {
                     const int c4n = (g + 1) / 2, rbn = (g + 1) % 2;
                     wino_lds_load(d[(g + 1) & 1], xb_addr + 4u * ((4 * c4n) * PLANE + (5 * rbn) * PC));
@@ -393,18 +395,14 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(nbuf + pc * 256), 16, 0, 0);
                 }
+                f32x2v v01[5], v23[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) wino_bt(v01[i], v23[i], d[g & 1][i][0], d[g & 1][i][1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const int ry = 5 * rb + i;
-                    f32x2v vn01 = vc01, vn23 = vc23;
-                    if (i < 4) {
-                        wino_bt(vn01, vn23, d[g & 1][i + 1][0], d[g & 1][i + 1][1]);
-                    } else if (g + 1 < NG) {
-                        wino_lds_wait(d[(g + 1) & 1]);          // issued a whole group ago
-                        wino_bt(vn01, vn23, d[(g + 1) & 1][0][0], d[(g + 1) & 1][0][1]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const float V[4] = {vc01.x, vc01.y, vc23.x, vc23.y};
+                    const float V[4] = {v01[i].x, v01[i].y, v23[i].x, v23[i].y};
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const int r = ry - dy;
@@ -417,9 +415,8 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
                             }
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    vc01 = vn01; vc23 = vn23;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (STAMP) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_compute += t - tp; tp = t; }
             __syncthreads();

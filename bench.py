@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- PnP-SVRG inner-iterations/s on 256x256 CSMRI (20 % sampling) + DnCNN-17 prox.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload dncnn|tv]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload dncnn|tv|saga-nlm]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one inner iteration of pnp_svrg (reference algorithms/pnp_svrg.py:41-94: minibatch
-SVRG direction via the masked-FFT gradient, step, estimate_sigma, DnCNN prox, PSNR error sum) for a
-batch of B independent reconstructions per GPU, including the outer full-gradient refresh every
-T2 = 10 steps.  Inputs (problems, network weights) are resident in HBM before the timed region; minibatches are drawn
-on the device inside each step.  Every rank runs its own B problems (weak scaling; the only
-collective is the final gather of results, after the timed region).
+One "step" = one inner iteration of pnp_svrg (reference algorithms/pnp_svrg.py:41-94: minibatch SVRG direction via
+the masked-FFT gradient, step, estimate_sigma, DnCNN prox, PSNR error sum) for a batch of B independent
+reconstructions per GPU, including the outer full-gradient refresh every T2 = 10 steps.  Inputs (problems, network
+weights) are resident in HBM before the timed region; minibatches are drawn on the device (one launch per outer
+iteration).  Masks are Bernoulli like the reference's (problems/CSMRI.py:43-45), so every problem has its own M0.
+Every rank runs its own B problems (weak scaling; the only collective is the final gather of results, after the
+timed region).
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel =
-the 64->64 3x3 conv on the f32 matrix cores) and `cpu_baseline` (the oracle, i.e. the CPU port of
-the reference path, timed on this box's host cores on a bounded sample).
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel = the 64->64 3x3
+conv on the f32 matrix cores; `frac` = EXECUTED MFMA FLOP/s over the f32 matrix peak), `cpu_baseline` (the oracle,
+i.e. the CPU port of the reference path, timed on this box's host cores on a bounded sample) and -- at N = 1 in the
+default configuration -- `secondary`: BASELINE configs 2 (TV prox, HBM-bound) and 4 (Deblur + NLM prox + pnp_saga)
+timed in the same run with their own `roofline` / `cpu_baseline`.
+
+`--gpus N` without torchrun (WORLD_SIZE unset) launches the N ranks itself (torch.distributed.run as a child process,
+before this process touches the GPU) and exits with its status.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,10 +38,16 @@ H = W = 256
 SAMPLE_PROB, SNR = 0.2, 20.0
 ETA, T2, MB = 2e3, 10, 1000
 NET_SIGMA = 15
-FLOP_MID_PER_IMAGE = 2 * 9 * 64 * 64 * H * W          # one 64->64 3x3 conv layer
+SAGA_ETA, SAGA_MB, SAGA_HIST, SAGA_SNR = 3e8, 3000, 50, 20.0    # the reference's blur has gain 1/sqrt(N): gradients are O(1e-9)
+FLOP_MID_PER_IMAGE = 2 * 9 * 64 * 64 * H * W          # one 64->64 3x3 conv layer, direct form
+WINOGRAD_REDUCTION = 1.5                               # F(2,3) along x executes 2/3 of the direct form's multiply-adds
 F32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0                         # same guide: ~2.5 PF dense bf16/f16 (only for --conv f16x3)
+F32_VALU_PEAK_TFLOPS = 157.3                          # same guide: vector f32 FMA peak (NLM prox)
 HBM_PEAK_GBS = 8000.0
+TV_BYTES_PER_ITER = 2368 * 1024                       # algorithmic bytes of one config-2 problem-iteration
+NLM_FLOP_PER_PIXEL = 121 * 25 * 5                     # 11x11 window x 5x5 patch x (sub, mul, sub, mul, add), before early exits
+SAGA_BYTES_PER_ITER = 8 * H * W * 4                   # table update: read g, old slot, prev, sum, z; write slot, sum, z
 
 
 def parse():
@@ -42,10 +55,12 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=120,
-                    help='independent reconstructions per GPU (default 120 = one Set12 x 10 sampling-ratio sweep, BASELINE config 5)')
-    ap.add_argument('--workload', default='dncnn', choices=['dncnn', 'tv'])
+    ap.add_argument('--batch', type=int, default=None,
+                    help='independent reconstructions per GPU (default: 120 = one Set12 x 10 sampling-ratio sweep for dncnn, '
+                         '256 for tv, 64 for saga-nlm)')
+    ap.add_argument('--workload', default='dncnn', choices=['dncnn', 'tv', 'saga-nlm'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the config-2 / config-4 secondary measurements')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo + PNP_BENCH_ONE_DEVICE=1 rehearses the N>1 path with all ranks on GPU 0')
     ap.add_argument('--graph', action='store_true',
@@ -54,10 +69,14 @@ def parse():
                     help='conv kernel of the DnCNN prox (default: f32-winograd, or PNP_DNCNN_WINOGRAD).  f16x3 = opt-in '
                          'split-fp16 products with fp32 accumulation (fp32-class accuracy, not the reference arithmetic): '
                          'the line then says dtype "f32 via 3 x f16 split" and prices the conv against the f16 matrix peak')
-    ap.add_argument('--fused-tv', action='store_true',
-                    help='tv workload: pnp_csmri_grad_prox_tv (one kernel for step + noise estimate + prox; measured slower)')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
     return ap.parse_args()
+
+
+def _synth_image(rng):
+    x = rng.random((H, W))
+    p5 = np.pad(x, 2, mode='wrap')
+    return sum(p5[i:i + H, j:j + W] for i in range(5) for j in range(5)) / 25.0
 
 
 def cpu_baseline(workload, weights, budget_s=12.0):
@@ -68,39 +87,222 @@ def cpu_baseline(workload, weights, budget_s=12.0):
     threads = min(torch.get_num_threads(), len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     np.random.seed(0)
-    rng = np.random.default_rng(0)
-    x = rng.random((H, W))
-    p5 = np.pad(x, 2, mode='wrap')
-    img = sum(p5[i:i + H, j:j + W] for i in range(5) for j in range(5)) / 25.0
-    p = op.CSMRI(None, H=H, W=W, sample_prob=SAMPLE_PROB, snr=SNR, img=img)
-    d = od.DnCNNDenoiser(weights, NET_SIGMA) if workload == 'dncnn' else od.TVDenoiser()
-    z = np.copy(p.Xinit)
-    mu = p.grad_full(z)
-    w = np.copy(z)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        if n % T2 == 0:
-            mu = p.grad_full(z)
-            w = np.copy(z)
-        mb = p.select_mb(MB)
-        v = (p.grad_stoch(z, mb) - p.grad_stoch(w, mb)) / MB + mu
-        z = z - ETA * v
-        z0 = z.reshape(H, W)
-        z0 = d.denoise(noisy=z0, sigma_est=od.estimate_sigma(z0))
-        p.PSNR(z0)
-        z = z0.ravel()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s and n >= 3:
-            break
+    img = _synth_image(np.random.default_rng(0))
+    if workload == 'saga-nlm':
+        p = op.Deblur(None, H=H, W=W, kernel='Minimal', scale_percent=100, snr=SAGA_SNR, img=img)
+        d = od.NLMDenoiser()
+        d.sigma = 1.0
+        z = np.copy(p.Xinit)
+        g0 = p.grad_stoch(z, p.select_mb(SAGA_MB)) / SAGA_MB
+        table, prev = [g0] * SAGA_HIST, g0
+        n, t0 = 0, time.perf_counter()
+        while True:
+            mb = p.select_mb(SAGA_MB)
+            r = np.random.choice(SAGA_HIST, 1).item()
+            table[r] = p.grad_stoch(z, mb) / SAGA_MB
+            v = table[r] - prev + sum(table) / SAGA_HIST
+            prev = table[r]
+            z = z - SAGA_ETA * v
+            z0 = z.reshape(H, W)
+            z0 = d.denoise(noisy=z0, sigma_est=od.estimate_sigma(z0))
+            p.PSNR(z0)
+            z = z0.ravel()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s and n >= 2:
+                break
+        what = f'{H}x{W} Deblur ("Minimal" kernel) + NLM prox, pnp_saga hist {SAGA_HIST}'
+    else:
+        p = op.CSMRI(None, H=H, W=W, sample_prob=SAMPLE_PROB, snr=SNR, img=img)
+        d = od.DnCNNDenoiser(weights, NET_SIGMA) if workload == 'dncnn' else od.TVDenoiser()
+        z = np.copy(p.Xinit)
+        mu = p.grad_full(z)
+        w = np.copy(z)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            if n % T2 == 0:
+                mu = p.grad_full(z)
+                w = np.copy(z)
+            mb = p.select_mb(MB)
+            v = (p.grad_stoch(z, mb) - p.grad_stoch(w, mb)) / MB + mu
+            z = z - ETA * v
+            z0 = z.reshape(H, W)
+            z0 = d.denoise(noisy=z0, sigma_est=od.estimate_sigma(z0))
+            p.PSNR(z0)
+            z = z0.ravel()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s and n >= 3:
+                break
+        what = f'{H}x{W} CSMRI + {workload} prox'
     return {'value': n / el, 'unit': 'inner-iters/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} inner iterations of 1 problem ({H}x{W} CSMRI + {workload} prox, oracle/ NumPy+torch-CPU fp32 net) in {el:.1f} s'}
+            'sample': f'{n} inner iterations of 1 problem ({what}, oracle/ NumPy' + ('+torch-CPU fp32 net' if workload == 'dncnn' else '') + f') in {el:.1f} s'}
+
+
+def _traffic(key):
+    tj = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tj):
+        try:
+            return json.load(open(tj)).get(key)
+        except Exception:
+            return None
+    return None
+
+
+class Workload:
+    """One configuration: builds the batch + engine, runs timed steps (device time from HIP events recorded on the
+    stream the kernels are launched on), produces its roofline object."""
+
+    def __init__(self, name, B, rank, a, weights=None):
+        from pnp_svrg_amd.engine import CsmriBatch, DeblurBatch, make_engine, DnCNNProx, TVProx, NLMProx
+        self.name, self.B, self.a = name, B, a
+        if name == 'saga-nlm':
+            self.batch = DeblurBatch.synthetic(B, H, W, 'Minimal', SAGA_SNR, seed=100 + rank)
+            self.prox = NLMProx()
+            self.eng = make_engine(self.batch, self.prox, SAGA_ETA, T2, SAGA_MB, algorithm='saga', hist_size=SAGA_HIST, seed=1 + rank)
+            self.mbsize = SAGA_MB
+        else:
+            self.batch = CsmriBatch.synthetic(B, H, W, SAMPLE_PROB, SNR, seed=100 + rank)
+            self.prox = DnCNNProx(weights, NET_SIGMA) if name == 'dncnn' else TVProx()
+            self.eng = make_engine(self.batch, self.prox, ETA, T2, MB, variant='svrg', seed=1 + rank)
+            self.mbsize = MB
+        self.n_draw = 0
+        self.idx = None
+        self.done = 0
+
+    def predraw(self, n):
+        self.n_draw = min(n, 64)
+        self.idx = self.batch.draw_minibatches(self.n_draw, self.mbsize, seed=7)
+
+    def run(self, n):
+        for _ in range(n):
+            if self.idx is not None:
+                self.eng.step(self.idx[self.done % self.n_draw])
+            else:
+                self.eng.step()
+            self.done += 1
+
+    def roofline(self, dt_step):
+        a, B = self.a, self.B
+        if self.name == 'dncnn':
+            ms, launches = self.prox.plan.profile_end()
+            flops = FLOP_MID_PER_IMAGE * B
+            alg = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            mode = os.environ.get('PNP_DNCNN_WINOGRAD', '1')
+            if mode == '3':
+                ex = 3.0 * alg                                  # three fp16 MFMAs per product
+                return {'bound': 'mfma',
+                        'kernel': 'pnp::k_mid_f16x3 (64->64 3x3 conv, every fp32 operand split into two fp16 terms, three '
+                                  'v_mfma_f32_16x16x32_f16 per product, fp32 accumulation; OPT-IN, not the reference arithmetic)',
+                        'achieved': round(ex, 2), 'peak': F16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(ex / F16_MFMA_PEAK_TFLOPS, 4), 'traffic': None, 'launch_ms': round(ms, 4),
+                        'launches_timed': launches, 'flops_per_launch': 3 * flops, 'algorithmic_tflops': round(alg, 2)}
+            wino = mode != '0'
+            red = WINOGRAD_REDUCTION if wino else 1.0
+            ex = alg / red
+            return {'bound': 'mfma',
+                    'kernel': ('pnp::k_mid_wino (64->64 3x3 conv, Winograd F(2,3) along x on v_mfma_f32_16x16x4_f32)' if wino
+                               else 'pnp::k_mid (64->64 3x3 conv, direct implicit GEMM on v_mfma_f32_16x16x4_f32)'),
+                    # achieved / frac: what the matrix cores EXECUTE per second against their peak
+                    'achieved': round(ex, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ex / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': _traffic(f'k_mid_B{B}'),
+                    'launch_ms': round(ms, 4), 'launches_timed': launches,
+                    'flops_per_launch': int(flops / red), 'algorithmic_flops_per_launch': flops,
+                    'algorithmic_tflops': round(alg, 2), 'winograd_reduction': red}
+        if self.name == 'tv':
+            # no single dominant kernel (rows_inv / prox / cols / rows_fwd ~ 20-27 % each): the whole step against HBM
+            alg = TV_BYTES_PER_ITER * B
+            ach = alg / dt_step / 1e9
+            return {'bound': 'hbm',
+                    'kernel': 'whole inner iteration (k_rows_fwd + k_cols<hashed minibatch> + k_rows_inv + k_prox_tv; 1/T2 of k_draw_thr)',
+                    'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                    'traffic': _traffic(f'tv_step_B{B}'), 'bytes_per_step': alg}
+        # saga-nlm: the NLM prox dominates (VALU-bound patch search); the table update is the HBM-bound part
+        ms = self.nlm_ms
+        fl = NLM_FLOP_PER_PIXEL * H * W * B
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {'bound': 'valu',
+                'kernel': 'pnp::k_nlm<float,5> (11x11 search window x 5x5 patches from an LDS-staged tile, f32; nominal FLOPs before '
+                          'the reference\'s early exits and border clipping)',
+                'achieved': round(ach, 2), 'peak': F32_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F32_VALU_PEAK_TFLOPS, 4),
+                'traffic': None, 'launch_ms': round(ms, 4), 'flops_per_launch': fl,
+                'saga_table_update': {'bound': 'hbm', 'bytes_per_step': SAGA_BYTES_PER_ITER * B,
+                                      'launch_ms': round(self.saga_ms, 4),
+                                      'achieved': round(SAGA_BYTES_PER_ITER * B / (self.saga_ms * 1e-3) / 1e9, 1) if self.saga_ms > 0 else None,
+                                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                      'frac': round(SAGA_BYTES_PER_ITER * B / (self.saga_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if self.saga_ms > 0 else None}}
+
+    def time_nlm_and_update(self, reps=5):
+        """HIP-event timing of the two config-4 kernels in isolation (torch events on the launch stream)."""
+        from pnp_svrg_amd import ops
+        eng, b = self.eng, self.batch
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        sse = torch.empty(b.B, dtype=torch.float64, device=b.device)
+        buf = torch.empty_like(eng.z)
+        ops.nlm2d(eng.z, sigma_in=self.prox.sig, xrec=b.xrec, out=buf, sse=sse)
+        torch.cuda.synchronize()
+        e[0].record()
+        for _ in range(reps):
+            ops.nlm2d(eng.z, sigma_in=self.prox.sig, xrec=b.xrec, out=buf, sse=sse)
+        e[1].record()
+        zc, ts = eng.z.clone(), eng.tsum.clone()
+        e[2].record()
+        for _ in range(reps):
+            ops.saga_table_update(zc, eng.g, eng.table[1], eng.table[0], ts, 0.0, 1.0 / eng.hist)
+        e[3].record()
+        torch.cuda.synchronize()
+        self.nlm_ms = e[0].elapsed_time(e[1]) / reps
+        self.saga_ms = e[2].elapsed_time(e[3]) / reps
+
+
+def measure(w, steps, warmup, sync_all, graph=False):
+    """warmup untimed steps, then exactly `steps` timed ones bracketed by sync (+ barrier); returns seconds."""
+    if graph:
+        w.eng.capture()
+        w.eng.run_outer(warmup // T2)
+    else:
+        w.run(warmup)
+    sync_all()
+    if w.name == 'dncnn' and not graph:
+        w.prox.plan.profile_begin(steps + 8)
+    t0 = time.perf_counter()
+    if graph:
+        w.eng.run_outer(steps // T2)
+    else:
+        w.run(steps)
+    sync_all()
+    return time.perf_counter() - t0
+
+
+def metric_name(workload):
+    return {'dncnn': 'PnP-SVRG inner-iters/sec, 256x256 CSMRI+DnCNN', 'tv': 'PnP-SVRG inner-iters/sec, 256x256 CSMRI+TV',
+            'saga-nlm': 'PnP-SAGA iters/sec, 256x256 Deblur+NLM'}[workload]
+
+
+def workload_desc(workload, wdesc):
+    if workload == 'saga-nlm':
+        return (f'pnp_saga (hist_size={SAGA_HIST}, mb={SAGA_MB}) on {H}x{W} Deblur ("Minimal" kernel, scale 100 %), NLM prox '
+                f'(patch 5x5, search 11x11)')
+    return (f'pnp_svrg (true SVRG direction, T2={T2}, mb={MB}) on {H}x{W} CSMRI, {int(SAMPLE_PROB * 100)}% Bernoulli mask, '
+            + (f'DnCNN-17 prox ({wdesc})' if workload == 'dncnn' else 'TV (Haar BayesShrink) prox'))
 
 
 def main():
     a = parse()
+    world_env = os.environ.get('WORLD_SIZE')
+    if a.gpus > 1 and world_env is None:
+        # launched the documented way without torchrun: start the N ranks as children (this process has not touched
+        # the GPU) and hand their status back
+        import socket
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f'[bench] --gpus {a.gpus} without WORLD_SIZE: launching {" ".join(cmd)}', file=sys.stderr)
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    world = int(world_env or '1')
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         import torch.distributed as dist
@@ -115,28 +317,20 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    if a.gpus != world and rank == 0 and world > 1:
+    if a.gpus != world and rank == 0:
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE {world}: using WORLD_SIZE', file=sys.stderr)
 
     if a.conv is not None:
         os.environ['PNP_DNCNN_WINOGRAD'] = {'f32-winograd': '1', 'f32-direct': '0', 'f16x3': '3'}[a.conv]
     from pnp_svrg_amd import ops
-    from pnp_svrg_amd.engine import CsmriBatch, make_engine, DnCNNProx, TVProx
     from pnp_svrg_amd.denoisers import random_dncnn_weights
     ops.require_gpu()
 
-    B = a.batch
+    B = a.batch if a.batch is not None else {'dncnn': 120, 'tv': 256, 'saga-nlm': 64}[a.workload]
     # the reference's own DnCNN sigma=15 weights (committed fixture) when present, else random init
     wfile = os.path.join(ROOT, 'tests', 'golden', 'dncnn_noise15.npz')
     weights = dict(np.load(wfile)) if os.path.exists(wfile) else random_dncnn_weights(17, seed=0)
     wdesc = 'reference DnCNN_noise15 weights' if os.path.exists(wfile) else 'random-init weights'
-    batch = CsmriBatch.synthetic(B, H, W, SAMPLE_PROB, SNR, seed=100 + rank)
-    prox = DnCNNProx(weights, NET_SIGMA) if a.workload == 'dncnn' else TVProx()
-    eng = make_engine(batch, prox, ETA, T2, MB, variant='svrg', seed=1 + rank, fused=bool(a.fused_tv and a.workload == 'tv'))
-    # minibatches are drawn ON THE DEVICE inside every step (pnp_csmri_draw_minibatch), like the reference
-    # draws them inside its timed gradient phase (pnp_svrg.py:52); --host-minibatches pre-draws index lists
-    n_draw = min(a.steps + a.warmup, 64)
-    idx = batch.draw_minibatches(n_draw, MB, seed=1 + rank) if a.host_minibatches else None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -144,88 +338,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    w = Workload(a.workload, B, rank, a, weights)
+    if a.host_minibatches:
+        w.predraw(a.steps + a.warmup)
     if a.graph:
-        assert idx is None, '--graph needs device-side minibatch draws'
+        assert w.idx is None and a.workload != 'saga-nlm', '--graph needs device-side minibatch draws and the SVRG engine'
         a.steps = -(-a.steps // T2) * T2
         a.warmup = -(-max(a.warmup, 1) // T2) * T2
-        eng.capture()
-        eng.run_outer(a.warmup // T2)
-    else:
-        for s in range(a.warmup):
-            eng.step(idx[s % n_draw] if idx is not None else None)
-    sync_all()
-    if a.workload == 'dncnn' and not a.graph:
-        prox.plan.profile_begin(a.steps + 8)
-    t0 = time.perf_counter()
-    if a.graph:
-        eng.run_outer(a.steps // T2)
-    else:
-        for s in range(a.steps):
-            eng.step(idx[(a.warmup + s) % n_draw] if idx is not None else None)
-    sync_all()
-    dt = time.perf_counter() - t0
+    dt = measure(w, a.steps, a.warmup, sync_all, a.graph)
     cdev = 'cuda' if (dist is None or a.backend == 'nccl') else 'cpu'      # where collective buffers live
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    roofline = None
-    if a.workload == 'dncnn' and not a.graph:
-        ms, launches = prox.plan.profile_end()
-        flops = FLOP_MID_PER_IMAGE * B
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get(f'k_mid_B{B}')
-            except Exception:
-                traffic = None
-        mode = os.environ.get('PNP_DNCNN_WINOGRAD', '1')
-        wino = mode not in ('0', '3')
-        if mode == '3':
-            executed = 3.0 * ach                                # three fp16 MFMAs per product
-            roofline = {'bound': 'mfma',
-                        'kernel': 'pnp::k_mid_f16x3 (64->64 3x3 conv, every fp32 operand split into two fp16 terms, three '
-                                  'v_mfma_f32_16x16x32_f16 per product, fp32 accumulation; OPT-IN, not the reference arithmetic)',
-                        'achieved': round(executed, 2), 'peak': F16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(executed / F16_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
-                        'launch_ms': round(ms, 4), 'launches_timed': launches, 'flops_per_launch': 3 * flops,
-                        'algorithmic_tflops': round(ach, 2)}
-        else:
-          roofline = {'bound': 'mfma',
-                    'kernel': ('pnp::k_mid_wino (64->64 3x3 conv, Winograd F(2,3) along x on v_mfma_f32_16x16x4_f32: 2/3 of the '
-                               'direct form\'s multiply-adds, so the ALGORITHMIC rate can exceed the matrix-core peak)') if wino
-                              else 'pnp::k_mid (64->64 3x3 conv, direct implicit GEMM on v_mfma_f32_16x16x4_f32)',
-                    'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                    'launch_ms': round(ms, 4), 'launches_timed': launches,
-                    'flops_per_launch': flops,
-                    # what the matrix cores actually execute (Winograd F(2,3) needs 2/3 of the multiply-adds)
-                    'executed_tflops': round(ach * (2.0 / 3.0 if wino else 1.0), 2),
-                    'executed_frac_of_mfma_peak': round(ach * (2.0 / 3.0 if wino else 1.0) / F32_MFMA_PEAK_TFLOPS, 4)}
-
-    if a.workload == 'tv':
-        # no single dominant kernel (rows_inv / prox / cols / rows_fwd ~ 20-27 % each): the whole step against HBM
-        alg = 2368 * 1024 * B                                    # 2 368 KiB per problem-iteration
-        ach = alg / (dt / a.steps) / 1e9
-        kern = ('whole inner iteration (k_draw_mb + k_rows_fwd + k_cols + ' +
-                ('k_rows_inv_prox: step, noise estimate, prox and error fused)' if a.fused_tv else 'k_rows_inv + k_prox_tv)'))
-        traffic = None
-        tj = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tj) and not a.fused_tv:
-            try:
-                traffic = json.load(open(tj)).get(f'tv_step_B{B}')     # PMC bytes of one whole step (all five kernels)
-            except Exception:
-                traffic = None
-        roofline = {'bound': 'hbm', 'kernel': kern,
-                    'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                    'traffic': traffic, 'bytes_per_step': alg}
+    if a.workload == 'saga-nlm':
+        w.time_nlm_and_update()
+    roofline = None if (a.graph and a.workload == 'dncnn') else w.roofline(dt / a.steps)
 
     # final gather of the results (the only collective on this path; outside the timed region)
-    trace = eng.psnr_trace()
-    psnr0 = float(np.mean(np.around(10 * np.log10(1.0 / ((batch.xinit - batch.xrec) ** 2).reshape(B, -1).mean(1).cpu().numpy()), 2)))
+    trace = w.eng.psnr_trace()
+    psnr0 = float(np.mean(w.batch.psnr_init()))
     final_psnr = torch.from_numpy(np.ascontiguousarray(trace[-1])).to(cdev)
     if dist is not None:
         gathered = [torch.empty_like(final_psnr) for _ in range(world)] if rank == 0 else None
@@ -235,25 +367,45 @@ def main():
         all_psnr = final_psnr.cpu().numpy()[None]
 
     if rank == 0:
+        secondary = None
+        if world == 1 and a.workload == 'dncnn' and not a.no_secondary and not a.graph and a.conv is None and a.batch is None:
+            # BASELINE configs 2 and 4 in the same run, each with its own roofline (and a short CPU baseline)
+            secondary = {}
+            del w.eng, w.prox, w.batch
+            torch.cuda.empty_cache()
+            for name, bb, st in (('tv', 256, 200), ('saga-nlm', 64, 20)):
+                w2 = Workload(name, bb, rank, a)
+                dt2 = measure(w2, st, 10 if name == 'tv' else 3, sync_all)
+                if name == 'saga-nlm':
+                    w2.time_nlm_and_update()
+                tr2 = w2.eng.psnr_trace()
+                secondary[name] = {'metric': metric_name(name), 'value': round(bb * st / dt2, 2), 'unit': 'inner-iters/s',
+                                   'steps': st, 'ms_per_step': round(dt2 / st * 1e3, 4), 'dtype': 'f32',
+                                   'config': {'workload': workload_desc(name, ''), 'batch_per_gpu': bb},
+                                   'roofline': w2.roofline(dt2 / st),
+                                   'cpu_baseline': None if a.no_cpu_baseline else cpu_baseline(name, None, budget_s=6.0),
+                                   'psnr_db': {'initial_mean': float(np.mean(w2.batch.psnr_init())),
+                                               'after_timed_steps_mean': float(np.mean(tr2[-1]))}}
+                del w2
+                torch.cuda.empty_cache()
         cpu = None
         if not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(a.workload, weights)
         value = world * B * a.steps / dt
         line = {
-            'metric': 'PnP-SVRG inner-iters/sec, 256x256 CSMRI+DnCNN' if a.workload == 'dncnn'
-                      else 'PnP-SVRG inner-iters/sec, 256x256 CSMRI+TV',
+            'metric': metric_name(a.workload),
             'value': round(value, 2), 'unit': 'inner-iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32 via 3 x f16 split products (opt-in)' if (a.workload == 'dncnn' and os.environ.get('PNP_DNCNN_WINOGRAD') == '3') else 'f32',
             'data': 'synthetic',
-            'config': {'workload': f'pnp_svrg (true SVRG direction, T2={T2}, mb={MB}) on {H}x{W} CSMRI, '
-                                   f'{int(SAMPLE_PROB * 100)}% mask, '
-                                   + (f'DnCNN-17 prox ({wdesc})' if a.workload == 'dncnn' else 'TV (Haar BayesShrink) prox'),
+            'config': {'workload': workload_desc(a.workload, wdesc),
                        'batch_per_gpu': B, 'problems_total': world * B, 'parallelism': f'replicas x{world} (no data-path collective)'},
             'roofline': roofline, 'cpu_baseline': cpu,
             'psnr_db': {'initial_mean': psnr0, 'after_timed_steps_mean': float(np.mean(all_psnr))},
         }
+        if secondary is not None:
+            line['secondary'] = secondary
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -43,13 +43,29 @@ int pnp_csmri_plan_destroy(pnp_csmri_plan* plan);
  * np.flatnonzero(mask) / problems/CSMRI.py:66-74 produce them.  idx: [batch][n] int32,
  * selT: [batch][W][H] uint8 (TRANSPOSED: the column pass reads along ky).              */
 int pnp_csmri_sel_from_indices(pnp_csmri_plan* plan, const int32_t* idx, int n, uint8_t* selT, void* stream);
-/* Device-side minibatch draw (problems/CSMRI.py:66-74 semantics: `mb` of the M0 sampled locations, uniform
- * without replacement) straight into the transposed selector: counter-based keys hash(seed, step, problem,
- * position), the mb smallest win (radix select).  mask_idx: [batch][M0] int32 = flatnonzero(mask) per problem.
+/* Bit-packed form of a transposed selector: bitsT [batch][W][H/32] uint32, bit (ky & 31) of word [kx][ky >> 5].
+ * The sampling mask is kept in this form (8 KiB per 256 x 256 problem instead of 64 KiB).               */
+int pnp_csmri_pack_mask(pnp_csmri_plan* plan, const uint8_t* selT, uint32_t* bitsT, void* stream);
+
+/* Device-side minibatch draw (problems/CSMRI.py:66-74 semantics: `mb` of the problem's sampled locations, uniform
+ * without replacement; problems of one batch may have different numbers of sampled locations).  Every sampled
+ * location i (flat row-major k-space index, as np.flatnonzero(mask) counts) gets the 32-bit key
+ *     key(i) = mix64(state + i) >> 32,  state = mix64(mix64(mix64(seed) + step) + problem),  mix64 = splitmix64
+ * and the mb smallest (key, i) pairs win.  Only the threshold pair is computed: descriptor {uint64 state; uint32 T;
+ * uint32 P} per (step, problem); i is in the minibatch iff key(i) < T or (key(i) == T and i <= P).  The gradient
+ * (pnp_csmri_grad_sel) re-derives membership from it, so no selector is ever written.  mbd: [nsteps][batch]
+ * descriptors (16 bytes each) for steps step0 .. step0 + nsteps - 1 -- a whole outer iteration in one launch.
  * Deterministic in (seed, step); NOT NumPy's legacy stream (reference-identical draws come from the host).
- * step_dev (may be NULL): device-resident counter added to `step`, so the call can be replayed from a hipGraph. */
-int pnp_csmri_draw_minibatch(pnp_csmri_plan* plan, const int32_t* mask_idx, int M0, int mb, uint64_t seed,
-                             uint32_t step, const uint32_t* step_dev, uint8_t* selT, void* stream);
+ * step_dev (may be NULL): device-resident counter added to `step0`, so the call can be replayed from a hipGraph.
+ * mb >= the number of sampled locations selects them all.                                                */
+int pnp_csmri_draw_thresholds(pnp_csmri_plan* plan, const uint32_t* bitsT, int mb, uint64_t seed, uint32_t step0,
+                              int nsteps, const uint32_t* step_dev, void* mbd, void* stream);
+/* mask o minibatch of ONE step as an explicit transposed selector (mbd: [batch] descriptors of that step).   */
+int pnp_csmri_sel_from_thresholds(pnp_csmri_plan* plan, const uint32_t* bitsT, const void* mbd, uint8_t* selT,
+                                  void* stream);
+/* pnp_csmri_draw_thresholds for one step followed by pnp_csmri_sel_from_thresholds (plan-owned descriptors).   */
+int pnp_csmri_draw_minibatch(pnp_csmri_plan* plan, const uint32_t* bitsT, int mb, uint64_t seed, uint32_t step,
+                             const uint32_t* step_dev, uint8_t* selT, void* stream);
 /* Same, from a dense row-major 0/1 indicator [batch][H][W] (uint8).                      */
 int pnp_csmri_sel_from_dense(pnp_csmri_plan* plan, const uint8_t* sel, uint8_t* selT, void* stream);
 
@@ -67,16 +83,18 @@ int pnp_csmri_grad(pnp_csmri_plan* plan, const void* a, const void* b, const uin
                    const void* yh, double alpha, double beta, const void* c1,
                    double gamma, const void* c2, void* out, void* stream);
 
-/* pnp_csmri_grad immediately followed by the TV prox (pnp_prox_tv with the noise estimate fused, i.e.
- * algorithms/pnp_svrg.py:53-80 = step, estimate_sigma, TVDenoiser.denoise, PSNR) in one pass over the image, for
- * callers that keep their images TRANSPOSED: the prox acts along the STORAGE ROWS (last axis) of `out`, which are the
- * image columns when a/b/c1/c2/out/xrec hold x^T (pass the selector and data term of the transposed problem, i.e. the
- * un-transposed mask where pnp_csmri_grad wants the transposed one).  f32 plans, 64 x 64 or 256 x 256.
- * sigma_modifier, fallback_sigma, xrec, sse_out, sigma_out as in pnp_prox_tv (sigma always estimated in-kernel).  */
-int pnp_csmri_grad_prox_tv(pnp_csmri_plan* plan, const void* a, const void* b, const uint8_t* selT, const void* yh,
-                           double alpha, double beta, const void* c1, double gamma, const void* c2, void* out,
-                           double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out,
-                           void* sigma_out, void* stream);
+/* The same gradient with the other selector forms and a per-problem scale.  Exactly one of
+ *   selT != NULL                   explicit transposed uint8 selector (as pnp_csmri_grad)
+ *   bitsT != NULL, mbd == NULL     the bit-packed sampling mask itself (grad_full)
+ *   bitsT != NULL, mbd != NULL     mask o device-drawn minibatch: mbd = this step's [batch] descriptors
+ * Data term: yh (packed for exactly this selector, pnp_csmri_pack_y) or YT ([batch][W][H] complex = Y transposed:
+ * the selector's data term is then formed inside the column pass, which is what a minibatch selector that exists
+ * only as a threshold needs -- grad_stoch of pnp_sgd.py:33 / pnp_saga.py:45); at most one of the two.
+ * alpha_vec (may be NULL): [batch] values of `dtype`; problem b uses alpha * alpha_vec[b] -- the 1/M0 of
+ * problems/CSMRI.py:81 when the masks of a batch have different counts (Bernoulli masks, CSMRI.py:43-45).    */
+int pnp_csmri_grad_sel(pnp_csmri_plan* plan, const void* a, const void* b, const uint8_t* selT, const uint32_t* bitsT,
+                       const void* mbd, const void* yh, const void* YT, double alpha, const void* alpha_vec, double beta,
+                       const void* c1, double gamma, const void* c2, void* out, void* stream);
 
 /* ------------------------------------------------------------------ Deblur / super-resolution
  * Replaces problems/DeblurSR.py:119-147: 1-D circular blur of the raveled image via a length-H*W FFT
@@ -94,6 +112,10 @@ int pnp_deblur_plan_destroy(pnp_deblur_plan* plan);
  * sel = minibatch indicator uint8 [batch][M], scale = 1).  z, out [batch][H*W]; Y [batch][M].   */
 int pnp_deblur_grad(pnp_deblur_plan* plan, const void* z, const void* Y, const uint8_t* sel, double scale,
                     void* out, void* stream);
+/* grad_stoch with a device-drawn minibatch: mbd = this step's [batch] threshold descriptors from
+ * pnp_draw_thresholds(M, ...); the indicator is re-derived where the residual is masked, never stored.   */
+int pnp_deblur_grad_mb(pnp_deblur_plan* plan, const void* z, const void* Y, const void* mbd, double scale,
+                       void* out, void* stream);
 /* forward model S B x (DeblurSR.py:110-112): out [batch][M]                                     */
 int pnp_deblur_forward(pnp_deblur_plan* plan, const void* x, void* out, void* stream);
 
@@ -104,6 +126,10 @@ int pnp_deblur_forward(pnp_deblur_plan* plan, const void* x, void* out, void* st
 size_t pnp_pr_workspace_elems(int M, int N);
 int pnp_pr_grad(const void* A, const void* w, const void* y, const int32_t* rows, int nsel, int M, int N,
                 int dtype, double scale, void* workspace, void* out, void* stream);
+/* B independent problems per call: A [batch][M][N], w [batch][N], y [batch][M], rows [batch][nsel] (NULL = all rows),
+ * out [batch][N]; workspace: batch * pnp_pr_workspace_elems(M, N) elements.                                  */
+int pnp_pr_grad_batch(const void* A, const void* w, const void* y, const int32_t* rows, int nsel, int M, int N, int batch,
+                      int dtype, double scale, void* workspace, void* out, void* stream);
 /* One power-iteration step of PhaseRetrieval.spec_init (problems/PR.py:50-63): out = scale * A^T (y o (A v)), i.e.
  * D v for D = A^T diag(y) A / M (scale = 1/M) without forming the N x N matrix.  v, out [N]; same workspace.      */
 int pnp_pr_spectral_apply(const void* A, const void* v, const void* y, int M, int N, int dtype, double scale,
@@ -196,6 +222,25 @@ int pnp_dncnn_debug_clock(pnp_dncnn_plan* plan, int reps, double* cycles, double
  * depends on a host-side step index).  pnp_log_append: log[(*step_dev % n_log)][0..n) = src[0..n).        */
 int pnp_counter_add(uint32_t* counter, uint32_t inc, void* stream);
 int pnp_log_append(const double* src, int n, double* log, int n_log, const uint32_t* step_dev, void* stream);
+
+/* ------------------------------------------------------------------ minibatches over M measurements, SAGA table
+ * Problem.select_mb (problems/problem.py:110-117: `np.random.choice(M, size, replace=False)` -> 0/1 indicator) on the
+ * device, with the same key / threshold construction as pnp_csmri_draw_thresholds (candidates 0 .. M-1):
+ * mbd [nsteps][batch] descriptors; the Deblur gradient consumes a step's descriptors directly (pnp_deblur_grad_mb),
+ * or they are expanded to an indicator sel [batch][M] (uint8) / an ascending row list rows [batch][mb] (int32, the
+ * form pnp_pr_grad takes).                                                                                */
+int pnp_draw_thresholds(int M, int batch, int mb, uint64_t seed, uint32_t step0, int nsteps, const uint32_t* step_dev,
+                        void* mbd, void* stream);
+int pnp_indicator_from_thresholds(int M, int batch, const void* mbd, uint8_t* sel, void* stream);
+int pnp_rows_from_thresholds(int M, int batch, int mb, const void* mbd, int32_t* rows, void* stream);
+/* indicator from host-drawn index lists (np.random.choice output): idx [batch][n] int32 -> sel [batch][M] uint8   */
+int pnp_indicator_from_indices(const int32_t* idx, int n, int M, int batch, uint8_t* sel, void* stream);
+/* One SAGA step (algorithms/pnp_saga.py:43-57) in one pass over the vectors (n = batch * N elements):
+ *   old = slot; sum += g - old; z -= lr * ((g - prev) + sum * inv_hist); slot = g
+ * g = the new minibatch gradient (already / mini_batch_size), slot = the table row being replaced, prev = the row
+ * written by the previous step (may be the same row), sum = running sum of the table (== sum(table), :47).   */
+int pnp_saga_table_update(void* z, const void* g, void* slot, const void* prev, void* sum, double lr, double inv_hist,
+                          size_t n, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ elementwise
  * out = a*x + b*y + c*w   (y, w may be NULL); n = total element count.

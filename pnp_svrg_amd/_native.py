@@ -22,19 +22,24 @@ SIGNATURES = {
     'pnp_csmri_plan_create': (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i]),
     'pnp_csmri_plan_destroy': (_i, [_vp]),
     'pnp_csmri_sel_from_indices': (_i, [_vp, _vp, _i, _vp, _vp]),
-    'pnp_csmri_draw_minibatch': (_i, [_vp, _vp, _i, _i, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, _vp]),
+    'pnp_csmri_pack_mask': (_i, [_vp, _vp, _vp, _vp]),
+    'pnp_csmri_draw_thresholds': (_i, [_vp, _vp, _i, ctypes.c_uint64, ctypes.c_uint32, _i, _vp, _vp, _vp]),
+    'pnp_csmri_sel_from_thresholds': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'pnp_csmri_draw_minibatch': (_i, [_vp, _vp, _i, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, _vp]),
     'pnp_counter_add': (_i, [_vp, ctypes.c_uint32, _vp]),
     'pnp_log_append': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     'pnp_csmri_sel_from_dense': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_csmri_pack_y': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pnp_csmri_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _d, _vp, _vp, _vp]),
-    'pnp_csmri_grad_prox_tv': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _d, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp]),
+    'pnp_csmri_grad_sel': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _d, _vp, _vp, _vp]),
     'pnp_deblur_plan_create': (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     'pnp_deblur_plan_destroy': (_i, [_vp]),
     'pnp_deblur_grad': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp]),
+    'pnp_deblur_grad_mb': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp]),
     'pnp_deblur_forward': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_pr_workspace_elems': (_sz, [_i, _i]),
     'pnp_pr_grad': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
+    'pnp_pr_grad_batch': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp]),
     'pnp_pr_spectral_apply': (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
     'pnp_sigma_est': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'pnp_prox_tv': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _d, _d, _vp, _vp, _vp, _vp]),
@@ -51,6 +56,11 @@ SIGNATURES = {
     'pnp_dncnn_profile_begin': (_i, [_vp, _i]),
     'pnp_dncnn_profile_end': (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(ctypes.c_long)]),
     'pnp_dncnn_debug_clock': (_i, [_vp, _i, ctypes.POINTER(_d), ctypes.POINTER(_d), _vp]),
+    'pnp_draw_thresholds': (_i, [_i, _i, _i, ctypes.c_uint64, ctypes.c_uint32, _i, _vp, _vp, _vp]),
+    'pnp_indicator_from_thresholds': (_i, [_i, _i, _vp, _vp, _vp]),
+    'pnp_rows_from_thresholds': (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    'pnp_indicator_from_indices': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'pnp_saga_table_update': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _sz, _i, _vp]),
     'pnp_axpbypcz': (_i, [_d, _vp, _d, _vp, _d, _vp, _vp, _sz, _i, _vp]),
 }
 

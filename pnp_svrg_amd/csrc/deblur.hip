@@ -17,6 +17,7 @@
 // a blur is 3 launches: k_colpass -> k_rowpass -> k_colpass (its real epilogue carries "- Y", the
 // minibatch mask and the scaling).
 #include "fft.h"
+#include "draw.h"
 #include <vector>
 #include <cmath>
 
@@ -41,7 +42,8 @@ template <typename T, int RA, int LA> struct LineSmem {
 template <typename T, int RA, int LA, bool INV, bool IN_REAL, bool TWIDDLE, bool OUT_REAL>
 __global__ __launch_bounds__(256) void k_colpass(const void* __restrict__ in_, void* __restrict__ out_,
                                                  const cx<T>* __restrict__ tw_line, const cx<T>* __restrict__ tw_big,
-                                                 T alpha, T beta, const T* __restrict__ c, const uint8_t* __restrict__ sel) {
+                                                 T alpha, T beta, const T* __restrict__ c, const uint8_t* __restrict__ sel,
+                                                 const MbDesc* __restrict__ mbd) {
     using S = LineSmem<T, RA, LA>;
     constexpr int N = S::N, G = S::G, LG = S::LG;
     __shared__ cx<T> smem[S::ELEMS];
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void k_colpass(const void* __restrict__ in_, v
             T o = alpha * val.x;
             if (c != nullptr) o += beta * c[i];
             if (sel != nullptr && sel[i] == 0) o = (T)0;
+            if (mbd != nullptr && !mb_member(mbd[prob], (uint32_t)(k1 * N + b0 + p))) o = (T)0;   // device-drawn minibatch
             ((T*)out_)[i] = o;
         } else {
             ((cx<T>*)out_)[i] = val;
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(256) void k_rowpass(const cx<T>* in, cx<T>* out, co
 // 4-tap sparse operator (pylops Bilinear forward / its CSR adjoint): out[m] = sum_t w[m][t] * x[idx[m][t]]
 template <typename T>
 __global__ void k_gather4(const T* __restrict__ x, const int32_t* __restrict__ idx, const T* __restrict__ w, int n_out,
-                          int n_in, T beta, const T* __restrict__ c, const uint8_t* __restrict__ sel, T* __restrict__ out) {
+                          int n_in, T beta, const T* __restrict__ c, const uint8_t* __restrict__ sel,
+                          const MbDesc* __restrict__ mbd, T* __restrict__ out) {
     const int prob = blockIdx.y;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_out) return;
@@ -145,6 +149,7 @@ __global__ void k_gather4(const T* __restrict__ x, const int32_t* __restrict__ i
     const size_t i = (size_t)prob * n_out + m;
     if (c != nullptr) o += beta * c[i];
     if (sel != nullptr && sel[i] == 0) o = (T)0;
+    if (mbd != nullptr && !mb_member(mbd[prob], (uint32_t)m)) o = (T)0;
     out[i] = o;
 }
 
@@ -179,7 +184,7 @@ template <typename T, int RA, int LA>
 int col_fwd(pnp_deblur_plan* p, const T* x, int batch, hipStream_t s) {
     constexpr int G = LineSmem<T, RA, LA>::G;
     k_colpass<T, RA, LA, false, true, true, false><<<dim3(p->n / G, batch), 256, 0, s>>>(
-        x, p->w0, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big, (T)0, (T)0, nullptr, nullptr);
+        x, p->w0, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big, (T)0, (T)0, nullptr, nullptr, nullptr);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }
@@ -187,7 +192,7 @@ int col_fwd(pnp_deblur_plan* p, const T* x, int batch, hipStream_t s) {
 // one blur: out = sel ? alpha * (x (*) kernel) * sqrt(N)-normalised + beta*c : 0
 template <typename T, int RA, int LA>
 int blur(pnp_deblur_plan* p, const T* x, bool conj_kernel, T alpha, T beta, const T* c, const uint8_t* sel, T* out,
-         hipStream_t s) {
+         hipStream_t s, const MbDesc* mbd = nullptr) {
     constexpr int G = LineSmem<T, RA, LA>::G;
     const int B = p->batch;
     int rc = col_fwd<T, RA, LA>(p, x, B, s);
@@ -200,26 +205,27 @@ int blur(pnp_deblur_plan* p, const T* x, bool conj_kernel, T alpha, T beta, cons
         k_rowpass<T, RA, LA, false, false><<<grid, 256, 0, s>>>(w0, w0, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big, (const cx<T>*)p->FB);
     PNP_CHECK_LAUNCH();
     k_colpass<T, RA, LA, true, false, false, true><<<grid, 256, 0, s>>>(w0, out, (const cx<T>*)p->tw_line, (const cx<T>*)p->tw_big,
-                                                                  alpha, beta, c, sel);
+                                                                  alpha, beta, c, sel, mbd);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }
 
 template <typename T, int RA, int LA>
-int run_grad(pnp_deblur_plan* p, const T* z, const T* Y, const uint8_t* sel, double scale, T* out, hipStream_t s) {
+int run_grad(pnp_deblur_plan* p, const T* z, const T* Y, const uint8_t* sel, double scale, T* out, hipStream_t s,
+             const MbDesc* mbd = nullptr) {
     const int N = p->N, B = p->batch;
     const T inv_sqrtN = (T)(1.0 / std::sqrt((double)N));           // Re ifft(.) * sqrt(N); the inverse carries 1/N
     T* res = (T*)p->r0;
     int rc;
     if (p->g_idx == nullptr) {
-        rc = blur<T, RA, LA>(p, z, false, inv_sqrtN, (T)-1, Y, sel, res, s);        // sel o (B z - Y)
+        rc = blur<T, RA, LA>(p, z, false, inv_sqrtN, (T)-1, Y, sel, res, s, mbd);   // sel o (B z - Y)
         if (rc) return rc;
     } else {
         T* blurred = (T*)p->r1;
         rc = blur<T, RA, LA>(p, z, false, inv_sqrtN, (T)0, nullptr, nullptr, blurred, s);
         if (rc) return rc;
         T* down = (T*)p->down;
-        k_gather4<T><<<dim3((p->M + 255) / 256, B), 256, 0, s>>>(blurred, p->g_idx, (const T*)p->g_w, p->M, N, (T)-1, Y, sel, down);
+        k_gather4<T><<<dim3((p->M + 255) / 256, B), 256, 0, s>>>(blurred, p->g_idx, (const T*)p->g_w, p->M, N, (T)-1, Y, sel, mbd, down);
         PNP_CHECK_LAUNCH();
         k_csr<T><<<dim3((N + 255) / 256, B), 256, 0, s>>>(down, p->a_rowptr, p->a_col, (const T*)p->a_val, N, p->M, res);
         PNP_CHECK_LAUNCH();
@@ -234,7 +240,7 @@ int run_forward(pnp_deblur_plan* p, const T* x, T* out, hipStream_t s) {
     T* blurred = (T*)p->r1;
     int rc = blur<T, RA, LA>(p, x, false, inv_sqrtN, (T)0, nullptr, nullptr, blurred, s);
     if (rc) return rc;
-    k_gather4<T><<<dim3((p->M + 255) / 256, p->batch), 256, 0, s>>>(blurred, p->g_idx, (const T*)p->g_w, p->M, p->N, (T)0, nullptr, nullptr, out);
+    k_gather4<T><<<dim3((p->M + 255) / 256, p->batch), 256, 0, s>>>(blurred, p->g_idx, (const T*)p->g_w, p->M, p->N, (T)0, nullptr, nullptr, nullptr, out);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }
@@ -271,6 +277,7 @@ extern "C" int pnp_deblur_plan_create(pnp_deblur_plan** out, int H, int W, int b
     PNP_CHECK_ARG(N == 65536 || N == 16384 || N == 4096, "H*W must be 65536 (256x256), 16384 (128x128) or 4096 (64x64)");
     PNP_CHECK_ARG(dtype == PNP_F32 || dtype == PNP_F64, "bad dtype");
     PNP_CHECK_ARG(batch >= 1 && M >= 1 && M <= N, "bad batch / M");
+    PNP_CHECK_ARG(g_idx == nullptr || (g_w && a_rowptr && a_col && a_val), "bilinear operator needs all five arrays");
     auto* p = new pnp_deblur_plan{};
     p->N = N; p->n = N == 65536 ? 256 : N == 16384 ? 128 : 64; p->NL = N == 65536 ? 16 : N == 16384 ? 12 : 8; p->batch = batch; p->dtype = dtype; p->M = M;
     const size_t rs = dtype == PNP_F32 ? 4 : 8, cs = 2 * rs;
@@ -292,7 +299,6 @@ extern "C" int pnp_deblur_plan_create(pnp_deblur_plan** out, int H, int W, int b
         }
     }
     if (e == hipSuccess && g_idx != nullptr) {
-        PNP_CHECK_ARG(g_w && a_rowptr && a_col && a_val, "bilinear operator needs all five arrays");
         const int nnz = a_rowptr[N];
         e = hipMalloc(&p->g_idx, (size_t)M * 4 * 4);
         if (e == hipSuccess) e = hipMemcpy(p->g_idx, g_idx, (size_t)M * 16, hipMemcpyHostToDevice);
@@ -355,6 +361,24 @@ extern "C" int pnp_deblur_grad(pnp_deblur_plan* p, const void* z, const void* Y,
     double* oo = (double*)out;
     return p->NL == 16 ? run_grad<double, 16, 16>(p, zz, yy, sel, scale, oo, s)
          : p->NL == 12 ? run_grad<double, 8, 16>(p, zz, yy, sel, scale, oo, s) : run_grad<double, 8, 8>(p, zz, yy, sel, scale, oo, s);
+}
+
+// the same with a device-drawn minibatch given as this step's threshold descriptors (pnp_draw_thresholds over M)
+extern "C" int pnp_deblur_grad_mb(pnp_deblur_plan* p, const void* z, const void* Y, const void* mbd, double scale,
+                                  void* out, void* stream) {
+    PNP_CHECK_ARG(p && z && Y && mbd && out, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const MbDesc* d = (const MbDesc*)mbd;
+    if (p->dtype == PNP_F32) {
+        const float *zz = (const float*)z, *yy = (const float*)Y;
+        float* oo = (float*)out;
+        return p->NL == 16 ? run_grad<float, 16, 16>(p, zz, yy, nullptr, scale, oo, s, d)
+             : p->NL == 12 ? run_grad<float, 8, 16>(p, zz, yy, nullptr, scale, oo, s, d) : run_grad<float, 8, 8>(p, zz, yy, nullptr, scale, oo, s, d);
+    }
+    const double *zz = (const double*)z, *yy = (const double*)Y;
+    double* oo = (double*)out;
+    return p->NL == 16 ? run_grad<double, 16, 16>(p, zz, yy, nullptr, scale, oo, s, d)
+         : p->NL == 12 ? run_grad<double, 8, 16>(p, zz, yy, nullptr, scale, oo, s, d) : run_grad<double, 8, 8>(p, zz, yy, nullptr, scale, oo, s, d);
 }
 
 // forward model S B x (DeblurSR.py:110-112), for problem setup / f(w); out real [batch][M]

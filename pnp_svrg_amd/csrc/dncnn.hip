@@ -451,170 +451,6 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino(const float* __restrict__ i
     }
 }
 
-// ------------------------------------------------------------------------------- Winograd, two waves per SIMD
-// At one wave per SIMD every non-MFMA instruction of the wave costs ~7 cycles of matrix-pipe issue (measured with
-// pnp_dncnn_debug_clock).  k_mid_wino2 halves the tile (4 rows x 32 columns) and keeps only the CURRENT K-half's
-// 96 transformed weights in registers (re-fetched from L2 at each phase start), so a wave fits in 256 registers
-// and TWO independent workgroups share each CU: while one wave re-fetches weights, waits at its barrier or runs
-// its epilogue, its SIMD partner (from the other workgroup, at a different point of its tile) keeps the matrix
-// pipe busy.
-constexpr int W2_TR = 4, W2_PR = W2_TR + 2;
-constexpr int W2_PLANE = W2_PR * PC;                         // 240 floats; 240 % 32 == 16: k-rows on disjoint banks
-constexpr int W2_CHUNKS = HALF_C * W2_PLANE / 4;             // 1920 16-byte chunks per K-half = 30 wave pieces
-constexpr int W2_PIECES = W2_CHUNKS / 64;                    // 30
-constexpr int W2_PPW = 8;                                    // pieces per wave (32 slots; 30, 31 move zeros)
-constexpr int W2_HALF_LDS = 4 * W2_PPW * 256;                // 8192 floats = 32 KB per LDS buffer
-constexpr int W2_U = (HALF_C / 4) * 3 * 4;                   // 96 transformed weights per K-half
-
-template <bool RELU>
-__global__ __launch_bounds__(256, 2) void k_mid_wino2(const float* __restrict__ in, float* __restrict__ out,
-                                                      const float* __restrict__ upack, const float* __restrict__ bias,
-                                                      const float* __restrict__ zeros, int H, int W, int ntiles) {
-    __shared__ float lds[2 * W2_HALF_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / W2_TR);
-    const float* ub = upack + (size_t)wv * WINO_U * 64;             // wave-uniform base of this wave's 2 x 96 weights
-
-    float bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = bias[16 * wv + 4 * (lane >> 4) + r];
-    const int lbase = (lane >> 4) * W2_PLANE + 2 * (lane & 15) + XOFF;
-    int loff[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) loff[r] = (16 * wv + 4 * (lane >> 4) + r) * H * W + 2 * (lane & 15);
-    int poff[W2_PPW], prc[W2_PPW];
-#pragma unroll
-    for (int i = 0; i < W2_PPW; ++i) {
-        const int q = (wv + 4 * i) * 64 + lane;
-        const int cin = q / 60, r = q - cin * 60;
-        const int ry = r / 10, cx4 = 4 * (r - ry * 10);
-        prc[i] = ry | (cx4 << 8);
-        poff[i] = (cin * H + ry) * W + cx4;
-    }
-
-    auto issue_piece = [&](int g, float* buf, const float* src0, int ty0, int tx0, bool valid) {
-        const int pc = wv + 4 * g;
-        const int y = ty0 - 1 + (prc[g] & 255), x = tx0 - 4 + (prc[g] >> 8);
-        const bool ok = valid & (pc < W2_PIECES) & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
-        const float* src = ok ? src0 + poff[g] : zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(buf + pc * 256), 16, 0, 0);
-    };
-
-    const TileWalk tw_ = tile_walk(ntiles);
-    int tile = tw_.first;
-    {
-        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
-        const int ty0 = (t2 / tiles_x) * W2_TR, tx0 = (t2 % tiles_x) * TC;
-        const float* src0 = in + (((size_t)b * C) * H + ty0 - 1) * (size_t)W + tx0 - 4;
-#pragma unroll
-        for (int g = 0; g < W2_PPW; ++g) issue_piece(g, lds, src0, ty0, tx0, tile < tw_.limit);
-    }
-    __syncthreads();
-
-    for (; tile < tw_.limit; tile += tw_.step) {
-        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
-        const int ty0 = (t2 / tiles_x) * W2_TR, tx0 = (t2 % tiles_x) * TC;
-        f32x4 acc[W2_TR][4];
-#pragma unroll
-        for (int r = 0; r < W2_TR; ++r)
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi) acc[r][xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float* nbuf = lds + (half ^ 1) * W2_HALF_LDS;
-            const int nt = tile + tw_.step;
-            const int nb = half == 0 ? b : nt / tiles_per_img;
-            const int n2 = nt - nb * tiles_per_img;
-            const int nty0 = half == 0 ? ty0 : (n2 / tiles_x) * W2_TR, ntx0 = half == 0 ? tx0 : (n2 % tiles_x) * TC;
-            const bool nvalid = half == 0 ? true : nt < tw_.limit;
-            const float* nsrc0 = in + (((size_t)nb * C + (half ^ 1) * HALF_C) * H + nty0 - 1) * (size_t)W + ntx0 - 4;
-
-            // this phase's transformed weights (96 x 256 B, L2-resident; the SIMD partner computes meanwhile)
-            // hand-issued (inline asm): 6 x 16 global_load_dword off one scalar base + lane offset + immediate.
-            // Left to the compiler these 96 tile-invariant loads are hoisted out of the tile loop and spilled.
-            float ureg[W2_U];
-            {
-                const int voff = lane * 4;
-#pragma unroll
-                for (int k = 0; k < W2_U / 16; ++k) {
-                    const float* ubk = ub + (half * W2_U + 16 * k) * 64;
-                    float* u = ureg + 16 * k;
-                    asm volatile(
-                        "global_load_dword %0, %16, %17\n"
-                        "global_load_dword %1, %16, %17 offset:256\n"
-                        "global_load_dword %2, %16, %17 offset:512\n"
-                        "global_load_dword %3, %16, %17 offset:768\n"
-                        "global_load_dword %4, %16, %17 offset:1024\n"
-                        "global_load_dword %5, %16, %17 offset:1280\n"
-                        "global_load_dword %6, %16, %17 offset:1536\n"
-                        "global_load_dword %7, %16, %17 offset:1792\n"
-                        "global_load_dword %8, %16, %17 offset:2048\n"
-                        "global_load_dword %9, %16, %17 offset:2304\n"
-                        "global_load_dword %10, %16, %17 offset:2560\n"
-                        "global_load_dword %11, %16, %17 offset:2816\n"
-                        "global_load_dword %12, %16, %17 offset:3072\n"
-                        "global_load_dword %13, %16, %17 offset:3328\n"
-                        "global_load_dword %14, %16, %17 offset:3584\n"
-                        "global_load_dword %15, %16, %17 offset:3840\n"
-                        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]),
-                          "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11]), "=&v"(u[12]), "=&v"(u[13]), "=&v"(u[14]), "=&v"(u[15])
-                        : "v"(voff), "s"(ubk)
-                        : "memory");
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-
-            int xb_off = half * W2_HALF_LDS + lbase;
-            asm volatile("" : "+v"(xb_off));
-            const float* xb = lds + xb_off;
-
-            constexpr int NG = HALF_C / 4;                      // 8 groups (one channel quad each) per half
-            // No software prefetch here: the LDS latency of a group's 12 reads is covered by the SIMD partner.
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                float d[W2_PR][4];
-#pragma unroll
-                for (int i = 0; i < W2_PR; ++i)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) d[i][t] = xb[(4 * g) * W2_PLANE + i * PC + t];
-                issue_piece(g, nbuf, nsrc0, nty0, ntx0, nvalid);
-#pragma unroll
-                for (int i = 0; i < W2_PR; ++i) {
-                    const float V[4] = {d[i][0] - d[i][2], d[i][1] + d[i][2], d[i][2] - d[i][1], d[i][1] - d[i][3]};
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int r = i - dy;
-                        if (r >= 0 && r < W2_TR) {
-#pragma unroll
-                            for (int xi = 0; xi < 4; ++xi)
-                                acc[r][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ureg[(g * 3 + dy) * 4 + xi], V[xi], acc[r][xi], 0, 0, 0);
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-        }
-
-        float* ob = out + (size_t)b * C * H * W + ty0 * W + tx0;
-#pragma unroll
-        for (int r = 0; r < W2_TR; ++r) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float m0 = acc[r][0][q], m1 = acc[r][1][q], m2 = acc[r][2][q], m3 = acc[r][3][q];
-                float2 v;
-                v.x = (m0 + m1 + m2) + bv[q];
-                v.y = (m1 - m2 - m3) + bv[q];
-                if (RELU) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; }
-                *reinterpret_cast<float2*>(ob + loff[q] + r * W) = v;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------- first layer
 // xt = ((z - lo) / (hi - lo)) * srange + sshift ; act[c] = relu(sum_t w[c][t] * xt[tap t])
 // MMO form (clamp01): xt = clamp(z, 0, 1); act[c] = leaky_relu(b[c] + sum_t ..., slope)   (MMODenoise.py:30,90-91)
@@ -954,11 +790,6 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
             else
                 k_mid<true, false, 0, true><<<grid, 256, 0, s>>>(src, dst, p->wpack + (size_t)l * 4 * 2 * KSTEPS_HALF * 64,
                                                                 p->bias + (size_t)l * C, p->zeros, H, W, ntiles, nullptr, p->slope);
-        } else if (p->use_wino == 2) {
-            const int nt2 = B * (H / W2_TR) * (W / TC);
-            const int g2 = nt2 < 2 * p->num_cu ? nt2 : 2 * p->num_cu;
-            k_mid_wino2<true><<<g2, 256, 0, s>>>(src, dst, p->upack + (size_t)l * 4 * WINO_U * 64, p->bias + (size_t)l * C,
-                                                 p->zeros, H, W, nt2);
         } else if (p->use_wino)
             k_mid_wino<true><<<grid, 256, 0, s>>>(src, dst, p->upack + (size_t)l * 4 * WINO_U * 64, p->bias + (size_t)l * C,
                                                   p->zeros, H, W, ntiles);
@@ -993,7 +824,8 @@ extern "C" int pnp_dncnn_set_affine(pnp_dncnn_plan* p, const float* b_first, flo
 
 extern "C" int pnp_dncnn_set_winograd(pnp_dncnn_plan* p, int enable) {
     PNP_CHECK_ARG(p != nullptr, "null plan");
-    p->use_wino = enable;                                  // 0 direct, 1 Winograd, 2 Winograd with two workgroups per CU
+    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 3, "mode must be 0 (direct), 1 (Winograd) or 3 (split-fp16)");
+    p->use_wino = enable;
     return PNP_OK;
 }
 

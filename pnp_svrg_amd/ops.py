@@ -50,13 +50,37 @@ class CsmriPlan:
         N.call('pnp_csmri_sel_from_indices', self._h, _p(idx), idx.shape[1], _p(out), _stream())
         return out
 
-    def draw_minibatch(self, mask_idx, mb, seed, step, out=None, step_dev=None):
-        """Device-side uniform draw of `mb` of each problem's sampled locations -> transposed selector.
-        mask_idx: int32 [B, M0] (flatnonzero(mask) per problem)."""
-        assert mask_idx.dtype == torch.int32 and mask_idx.shape[0] == self.B
-        out = out if out is not None else torch.empty((self.B, self.W, self.H), dtype=torch.uint8, device=mask_idx.device)
-        N.call('pnp_csmri_draw_minibatch', self._h, _p(mask_idx), mask_idx.shape[1], int(mb), int(seed) & (2 ** 64 - 1),
-               int(step) & 0xFFFFFFFF, _p(step_dev), _p(out), _stream())
+    def pack_mask(self, selT, out=None):
+        """uint8 transposed selector [B, W, H] -> bit-packed mask int32 [B, W, H/32] (pnp_csmri_pack_mask)."""
+        assert selT.dtype == torch.uint8 and tuple(selT.shape) == (self.B, self.W, self.H)
+        out = out if out is not None else torch.empty((self.B, self.W, self.H // 32), dtype=torch.int32, device=selT.device)
+        N.call('pnp_csmri_pack_mask', self._h, _p(selT), _p(out), _stream())
+        return out
+
+    def draw_thresholds(self, bits, mb, seed, step0, nsteps=1, out=None, step_dev=None):
+        """Device-side minibatch draws for steps step0 .. step0+nsteps-1 of every problem: only the threshold
+        descriptors (int64 [nsteps, B, 2] = 16 bytes per (step, problem)); `grad(bits=, mbd=out[j])` consumes them."""
+        assert bits.dtype == torch.int32 and tuple(bits.shape) == (self.B, self.W, self.H // 32)
+        out = out if out is not None else torch.empty((nsteps, self.B, 2), dtype=torch.int64, device=bits.device)
+        assert out.dtype == torch.int64 and tuple(out.shape) == (nsteps, self.B, 2)
+        N.call('pnp_csmri_draw_thresholds', self._h, _p(bits), int(mb), int(seed) & (2 ** 64 - 1), int(step0) & 0xFFFFFFFF,
+               int(nsteps), _p(step_dev), _p(out), _stream())
+        return out
+
+    def sel_from_thresholds(self, bits, mbd, out=None):
+        """mask o minibatch of one step (mbd: int64 [B, 2]) as an explicit transposed uint8 selector."""
+        assert mbd.dtype == torch.int64 and tuple(mbd.shape) == (self.B, 2)
+        out = out if out is not None else torch.empty((self.B, self.W, self.H), dtype=torch.uint8, device=bits.device)
+        N.call('pnp_csmri_sel_from_thresholds', self._h, _p(bits), _p(mbd), _p(out), _stream())
+        return out
+
+    def draw_minibatch(self, bits, mb, seed, step, out=None, step_dev=None):
+        """Device-side uniform draw of `mb` of each problem's sampled locations -> explicit transposed selector.
+        bits: int32 [B, W, H/32] bit-packed mask (pack_mask)."""
+        assert bits.dtype == torch.int32 and tuple(bits.shape) == (self.B, self.W, self.H // 32)
+        out = out if out is not None else torch.empty((self.B, self.W, self.H), dtype=torch.uint8, device=bits.device)
+        N.call('pnp_csmri_draw_minibatch', self._h, _p(bits), int(mb), int(seed) & (2 ** 64 - 1), int(step) & 0xFFFFFFFF,
+               _p(step_dev), _p(out), _stream())
         return out
 
     def sel_from_dense(self, sel, out=None):
@@ -72,27 +96,22 @@ class CsmriPlan:
         N.call('pnp_csmri_pack_y', self._h, _p(YT), _p(selT), _p(out), _stream())
         return out
 
-    def grad(self, a, selT, b=None, yh=None, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None):
-        """out = alpha * Re ifft2(sel o fft2(a - b) - sel o Y) + beta*c1 + gamma*c2."""
+    def grad(self, a, selT=None, b=None, yh=None, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None, *,
+             bits=None, mbd=None, alpha_vec=None, YT=None):
+        """out = alpha * alpha_vec[b] * Re ifft2(sel o fft2(a - b) - sel o Y) + beta*c1 + gamma*c2.
+        Selector: `selT` (explicit uint8 [B, W, H]) or `bits` (bit-packed mask; with `mbd` = one step's draw
+        descriptors the selector is mask o minibatch, re-derived inside the kernel).  Data term: `yh` (packed for this
+        selector) or `YT` (complex [B, W, H], masked by the selector inside the kernel)."""
         for t in (a, b, c1, c2, out):
             assert t is None or (t.dtype == self.dtype and t.numel() == self.B * self.H * self.W)
+        assert (selT is None) != (bits is None), 'pass selT or bits'
+        assert alpha_vec is None or (alpha_vec.dtype == self.dtype and alpha_vec.numel() == self.B)
+        assert mbd is None or (mbd.dtype == torch.int64 and tuple(mbd.shape) == (self.B, 2))
         out = out if out is not None else torch.empty_like(a)
-        N.call('pnp_csmri_grad', self._h, _p(a), _p(b), _p(selT), _p(yh), float(alpha), float(beta), _p(c1),
-               float(gamma), _p(c2), _p(out), _stream())
+        assert YT is None or (YT.dtype == _CDT[self.dtype] and tuple(YT.shape) == (self.B, self.W, self.H))
+        N.call('pnp_csmri_grad_sel', self._h, _p(a), _p(b), _p(selT), _p(bits), _p(mbd), _p(yh), _p(YT), float(alpha), _p(alpha_vec),
+               float(beta), _p(c1), float(gamma), _p(c2), _p(out), _stream())
         return out
-
-    def grad_prox_tv(self, a, selT, b=None, yh=None, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None,
-                     sigma_modifier=1.0, fallback_sigma=0.0, xrec=None, sse=None, sigma_out=None):
-        """pnp_csmri_grad_prox_tv: `grad` immediately followed by the TV prox along the LAST axis of the stored
-        arrays (callers keep their images transposed), one pass over the image.  Returns (out, sse, sigma_est)."""
-        out = out if out is not None else torch.empty_like(a)
-        if xrec is not None and sse is None:
-            sse = torch.empty(self.B, dtype=torch.float64, device=a.device)
-        sigma_out = sigma_out if sigma_out is not None else torch.empty(self.B, dtype=a.dtype, device=a.device)
-        N.call('pnp_csmri_grad_prox_tv', self._h, _p(a), _p(b), _p(selT), _p(yh), float(alpha), float(beta), _p(c1),
-               float(gamma), _p(c2), _p(out), float(sigma_modifier), float(fallback_sigma), _p(xrec), _p(sse),
-               _p(sigma_out), _stream())
-        return out, sse, sigma_out
 
 
 class DncnnPlan:
@@ -295,10 +314,17 @@ class DeblurPlan:
             except Exception:
                 pass
 
-    def grad(self, z, Y, sel=None, scale=1.0, out=None):
+    def grad(self, z, Y, sel=None, scale=1.0, out=None, mbd=None):
+        """scale * B^T S^T (sel o (S B z - Y)); sel: uint8 [B, M] indicator, or mbd: int64 [B, 2] = one step's
+        device-drawn minibatch descriptors (draw_thresholds), or neither (all measurements)."""
         assert z.dtype == self.dtype and z.numel() == self.B * self.N and Y.numel() == self.B * self.M
+        assert sel is None or mbd is None
         out = out if out is not None else torch.empty_like(z)
-        N.call('pnp_deblur_grad', self._h, _p(z), _p(Y), _p(sel), float(scale), _p(out), _stream())
+        if mbd is not None:
+            assert mbd.dtype == torch.int64 and tuple(mbd.shape) == (self.B, 2)
+            N.call('pnp_deblur_grad_mb', self._h, _p(z), _p(Y), _p(mbd), float(scale), _p(out), _stream())
+        else:
+            N.call('pnp_deblur_grad', self._h, _p(z), _p(Y), _p(sel), float(scale), _p(out), _stream())
         return out
 
     def forward(self, x, out=None):
@@ -317,6 +343,63 @@ def pr_grad(A, w, y, rows=None, scale=1.0, workspace=None, out=None):
     nsel = M if rows is None else rows.numel()
     N.call('pnp_pr_grad', _p(A), _p(w), _p(y), _p(rows), nsel, M, Nn, _DT[A.dtype], float(scale), _p(workspace), _p(out), _stream())
     return out
+
+
+def pr_grad_batch(A, w, y, rows=None, scale=1.0, workspace=None, out=None):
+    """B independent problems: A [B,M,N], w [B,N], y [B,M], rows int32 [B,nsel] or None -> [B,N]."""
+    require_gpu()
+    B, M, Nn = A.shape
+    if workspace is None:
+        workspace = torch.empty(B * N.lib().pnp_pr_workspace_elems(M, Nn), dtype=A.dtype, device=A.device)
+    out = out if out is not None else torch.empty((B, Nn), dtype=A.dtype, device=A.device)
+    nsel = M if rows is None else rows.shape[1]
+    N.call('pnp_pr_grad_batch', _p(A), _p(w), _p(y), _p(rows), nsel, M, Nn, B, _DT[A.dtype], float(scale), _p(workspace),
+           _p(out), _stream())
+    return out
+
+
+def draw_thresholds(M, B, mb, seed, step0, nsteps=1, out=None, step_dev=None, device='cuda'):
+    """Device-side draws of `mb` of M measurements for B problems and `nsteps` steps -> descriptors int64 [nsteps, B, 2]."""
+    require_gpu()
+    out = out if out is not None else torch.empty((nsteps, B, 2), dtype=torch.int64, device=device)
+    N.call('pnp_draw_thresholds', int(M), int(B), int(mb), int(seed) & (2 ** 64 - 1), int(step0) & 0xFFFFFFFF, int(nsteps),
+           _p(step_dev), _p(out), _stream())
+    return out
+
+
+def indicator_from_thresholds(M, mbd, out=None):
+    require_gpu()
+    B = mbd.shape[0]
+    out = out if out is not None else torch.empty((B, M), dtype=torch.uint8, device=mbd.device)
+    N.call('pnp_indicator_from_thresholds', int(M), int(B), _p(mbd), _p(out), _stream())
+    return out
+
+
+def rows_from_thresholds(M, mb, mbd, out=None):
+    require_gpu()
+    B = mbd.shape[0]
+    out = out if out is not None else torch.empty((B, mb), dtype=torch.int32, device=mbd.device)
+    N.call('pnp_rows_from_thresholds', int(M), int(B), int(mb), _p(mbd), _p(out), _stream())
+    return out
+
+
+def indicator_from_indices(idx, M, out=None):
+    """idx int32 [B, n] -> uint8 [B, M] (Problem.select_mb's 0/1 indicator, problems/problem.py:110-117)."""
+    require_gpu()
+    assert idx.dtype == torch.int32
+    B, n = idx.shape
+    out = out if out is not None else torch.empty((B, M), dtype=torch.uint8, device=idx.device)
+    N.call('pnp_indicator_from_indices', _p(idx), int(n), int(M), int(B), _p(out), _stream())
+    return out
+
+
+def saga_table_update(z, g, slot, prev, tsum, lr, inv_hist):
+    """pnp_saga_table_update: one SAGA step over all elements (z, slot, tsum updated in place)."""
+    require_gpu()
+    for t in (g, slot, prev, tsum):
+        assert t.dtype == z.dtype and t.numel() == z.numel()
+    N.call('pnp_saga_table_update', _p(z), _p(g), _p(slot), _p(prev), _p(tsum), float(lr), float(inv_hist), z.numel(),
+           _DT[z.dtype], _stream())
 
 
 def pr_spectral_apply(A, v, y, scale=1.0, workspace=None, out=None):

@@ -33,7 +33,7 @@ def get_default_dtype():
 class Problem():
     """reference problems/problem.py:8-129."""
 
-    def __init__(self, img_path, H, W, *, img=None, dtype=None, device='cuda:0'):
+    def __init__(self, img_path, H, W, *, img=None, dtype=None, device='cuda:0', upload=True):
         self.H = H
         self.W = W
         self.N = H * W
@@ -49,11 +49,17 @@ class Problem():
         self.Xrec = tmp
         self.X = tmp.ravel()
         self.Xinit = np.empty_like(self.X)
-        # device side
-        ops.require_gpu()
+        # device side (upload=False: host-side construction only -- the batched engines upload whole batches)
         self.dtype = dtype if dtype is not None else _DEFAULT_DTYPE
         self.device = torch.device(device)
-        self._xrec_d = self.to_device(self.Xrec).reshape(1, H, W)
+        self._upload_enabled = upload
+        if upload:
+            ops.require_gpu()
+            if self.device.type == 'cuda' and self.device.index not in (None, torch.cuda.current_device()):
+                # plans allocate on, and kernels launch on, the CURRENT HIP device
+                raise Exception(f'device {self.device} is not the current device (cuda:{torch.cuda.current_device()}); '
+                                'call torch.cuda.set_device first')
+            self._xrec_d = self.to_device(self.Xrec).reshape(1, H, W)
 
     # ---- host <-> device helpers (extensions)
     def to_device(self, a):
@@ -175,7 +181,8 @@ class CSMRI(Problem):
         self.lrH, self.lrW = self.H, self.W
         self.M = self.N
         self.M0 = np.count_nonzero(self.mask)
-        self._upload()
+        if self._upload_enabled:
+            self._upload()
 
     def _generate_mask(self):
         self.mask = np.random.choice([0, 1], size=(self.H, self.W), p=[1 - self.sample_prob, self.sample_prob])
@@ -199,7 +206,6 @@ class CSMRI(Problem):
         self._maskT = self.plan.sel_from_indices(idx)
         self._yh_full = self.plan.pack_y(self._YT, self._maskT)
         self._selT = torch.empty_like(self._maskT)
-        self._yh = torch.empty_like(self._yh_full)
 
     def select_mb(self, size):
         if size > self.M:
@@ -224,8 +230,7 @@ class CSMRI(Problem):
     def grad_stoch(self, z, mb, *, scale=1.0):
         zd = (z if self._is_dev(z) else self.to_device(z)).reshape(1, self.H, self.W)
         selT = self._selector(mb)
-        yh = self.plan.pack_y(self._YT, selT, out=self._yh)
-        g = self.plan.grad(zd, selT, yh=yh, alpha=scale)
+        g = self.plan.grad(zd, selT, YT=self._YT, alpha=scale)      # the selector's data term is formed in the column pass
         return self._ret(g.reshape(-1), z)
 
     def grad_stoch_diff(self, z, w, mb, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None):

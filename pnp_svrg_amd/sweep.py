@@ -27,7 +27,9 @@ def make_items(n_images, alphas, snrs, seeds=(0,)):
 
 
 def shard(items, rank, world):
-    """Static round-robin: item i -> rank i % world (items of equal cost; no exchange afterwards)."""
+    """Static round-robin: item i -> rank i % world (items of equal cost; no exchange afterwards).  A rank's items
+    are batched TOGETHER whatever their sampling ratio (per-problem 1/M0 and minibatch thresholds in the engine), so
+    120 items on 8 ranks are 8 batches of 15, not 40 batches of 3."""
     return [it for it in items if it['id'] % world == rank]
 
 
@@ -56,45 +58,67 @@ def run_sweep(items, runner, group=None):
     return gather_results(res, 0, group)
 
 
+def _csmri_item_generator(img, it, H, W):
+    """One work item's data from a Generator stream keyed by the item (fast path of the sweeps): Bernoulli mask like
+    the reference (problems/CSMRI.py:43-45), masked spectrum + real noise on the support (:29-33), |ifft2| init."""
+    rng = np.random.default_rng(1000003 * it['seed'] + it['id'])
+    x = np.asarray(img, np.float64)
+    x = (x - x.min()) / (x.max() - x.min())
+    mk = (rng.random((H, W)) < it['alpha']).astype(np.uint8)
+    Y0 = mk * np.fft.fft2(x)
+    sig = np.sqrt(np.linalg.norm(Y0.ravel()) / 10 ** (it['snr'] / 10) / H / W)
+    Y = Y0 + mk * rng.normal(0, sig, (H, W))
+    xi = np.absolute(np.fft.ifft2(Y))
+    return x, mk, Y, ((xi - xi.min()) / (xi.max() - xi.min())).ravel()
+
+
 def csmri_svrg_runner(images, denoiser_factory, eta, T2, mini_batch_size, n_inner, H=256, W=256, dtype=torch.float32,
-                      max_batch=64):
+                      max_batch=128, seeding='generator', algorithm='svrg', variant='svrg', run_seed=1, keep_trace=False):
     """Default runner: CSMRI + pnp_svrg (true SVRG direction) on the batched engine.
-    images: list of HxW arrays; items with the same alpha are batched together (equal M0 per batch)."""
+    images: list of HxW arrays.  ALL of a rank's items -- any mix of sampling ratios, i.e. masks with different
+    numbers of sampled points -- go through the engine together (chunks of max_batch): per-problem 1/M0 and
+    per-problem minibatch thresholds make the batch independent of alpha.
+    seeding='generator': per-item data from a Generator stream, minibatches drawn on the device;
+    seeding='legacy'   : per item exactly what the reference does -- np.random.seed(item seed), the CSMRI constructor's
+                         draws in its order (mask, noise; problems/CSMRI.py:12-41), then np.random.seed(run_seed) and one
+                         select_mb draw per inner iteration (algorithms/pnp_svrg.py:52) from the legacy stream -- so an
+                         item's trajectory equals the reference loop's (and the oracle's) on the same seeds."""
     from .engine import CsmriBatch, make_engine
+    from . import problems as P
 
     def run(items):
         results = []
-        by_alpha = {}
-        for it in items:
-            by_alpha.setdefault(it['alpha'], []).append(it)
-        for alpha, group in by_alpha.items():
-            for s0 in range(0, len(group), max_batch):
-                chunk = group[s0:s0 + max_batch]
-                xs, masks, Ys, xinits = [], [], [], []
-                m0 = int(round(alpha * H * W))
-                for it in chunk:
-                    rng = np.random.default_rng(1000003 * it['seed'] + it['id'])
-                    x = np.asarray(images[it['image']], np.float64)
-                    x = (x - x.min()) / (x.max() - x.min())
-                    mk = np.zeros(H * W, np.uint8)
-                    mk[rng.choice(H * W, m0, replace=False)] = 1
-                    mk = mk.reshape(H, W)
-                    Y0 = mk * np.fft.fft2(x)
-                    sig = np.sqrt(np.linalg.norm(Y0.ravel()) / 10 ** (it['snr'] / 10) / H / W)
-                    Y = Y0 + mk * rng.normal(0, sig, (H, W))
-                    xi = np.absolute(np.fft.ifft2(Y))
-                    xs.append(x); masks.append(mk); Ys.append(Y); xinits.append((xi - xi.min()) / (xi.max() - xi.min()))
-                batch = CsmriBatch(np.stack(xs), np.stack(masks), np.stack(Ys), np.stack(xinits).reshape(len(chunk), -1), dtype=dtype)
-                eng = make_engine(batch, denoiser_factory(), eta, T2, mini_batch_size, variant='svrg')
-                idx = batch.draw_minibatches(n_inner, mini_batch_size, seed=chunk[0]['id'] + 1)
-                for s in range(n_inner):
-                    eng.step(idx[s])
-                tr = eng.psnr_trace()
-                psnr0 = np.around(10 * np.log10(1.0 / ((batch.xinit - batch.xrec) ** 2).reshape(len(chunk), -1).mean(1).double().cpu().numpy()), 2)
-                z = eng.z.cpu().numpy()
+        for s0 in range(0, len(items), max_batch):
+            chunk = items[s0:s0 + max_batch]
+            xs, masks, Ys, xinits, idx = [], [], [], [], None
+            if seeding == 'legacy':
+                idx = np.empty((n_inner, len(chunk), mini_batch_size), np.int32)
                 for j, it in enumerate(chunk):
-                    results.append({'id': it['id'], 'item': it, 'psnr_init': float(psnr0[j]), 'psnr_final': float(tr[-1, j]),
-                                    'loss': float(psnr0[j] - tr[-1, j]), 'z': z[j]})
+                    np.random.seed(it['seed'])
+                    p = P.CSMRI(None, H=H, W=W, sample_prob=it['alpha'], snr=it['snr'], img=images[it['image']], upload=False)
+                    xs.append(p.Xrec); masks.append(p.mask); Ys.append(p.Y); xinits.append(p.Xinit)
+                    np.random.seed(run_seed)
+                    for s in range(n_inner):
+                        idx[s, j] = np.flatnonzero(p.select_mb(mini_batch_size))
+            else:
+                for it in chunk:
+                    x, mk, Y, xi = _csmri_item_generator(images[it['image']], it, H, W)
+                    xs.append(x); masks.append(mk); Ys.append(Y); xinits.append(xi)
+            batch = CsmriBatch(np.stack(xs), np.stack(masks), np.stack(Ys), np.stack(xinits).reshape(len(chunk), -1), dtype=dtype)
+            eng = make_engine(batch, denoiser_factory(), eta, T2, mini_batch_size, variant=variant, algorithm=algorithm,
+                              seed=chunk[0]['id'] + 1)
+            idx_d = torch.from_numpy(idx).to(batch.device) if idx is not None else None
+            for s in range(n_inner):
+                eng.step(idx_d[s]) if idx_d is not None else eng.step()
+            tr = eng.psnr_trace()
+            psnr0 = batch.psnr_init()
+            z = eng.z.cpu().numpy()
+            for j, it in enumerate(chunk):
+                r = {'id': it['id'], 'item': it, 'psnr_init': float(psnr0[j]), 'psnr_final': float(tr[-1, j]),
+                     'loss': float(psnr0[j] - tr[-1, j]), 'z': z[j], 'M0': int(batch.M0[j])}
+                if keep_trace:
+                    r['psnr_trace'] = tr[:, j].copy()
+                results.append(r)
         return sorted(results, key=lambda r: r['id'])
     return run
 

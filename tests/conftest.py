@@ -50,3 +50,8 @@ def g_pr():
 @pytest.fixture(scope='session')
 def g_psnr():
     return golden('psnr.npz')
+
+
+@pytest.fixture(scope='session')
+def g_r2():
+    return golden('r2_fixtures.npz')

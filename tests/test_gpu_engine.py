@@ -1,4 +1,4 @@
-"""Batched engine == B independent drop-in loops (same minibatches), and bench plumbing."""
+"""Batched engines == B independent drop-in loops (same minibatches), device draws, and bench plumbing."""
 import numpy as np
 import pytest
 import torch
@@ -6,15 +6,45 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def dropin_csmri(batch, b):
+    """Problem b of a CsmriBatch as a drop-in `problems.CSMRI` (same device data, B = 1 plan)."""
+    import problems
+    n = batch.H
+    p = problems.CSMRI.__new__(problems.CSMRI)
+    problems.Problem.__init__(p, None, n, n, img=batch.xrec[b].cpu().numpy(), dtype=batch.dtype)
+    p.pname, p.mask, p.M0, p.M = 'csmri', batch.mask_np[b].astype(int), int(batch.M0[b]), n * n
+    p.Xrec = batch.xrec[b].cpu().numpy()
+    p._xrec_d = batch.xrec[b:b + 1].clone()
+    p.Xinit = batch.xinit[b].double().cpu().numpy().ravel()
+    p.Y = None
+    p.plan = batch.plan.__class__(n, n, 1, batch.dtype)
+    p._maskT = batch.maskT[b:b + 1].clone()
+    p._YT = batch.YT[b:b + 1].clone()
+    p._yh_full = batch.yh_full[b:b + 1].clone()
+    p._selT = torch.empty_like(p._maskT)
+    return p
+
+
+def feed_minibatches(p, lists, shape):
+    """Make p.select_mb return the given index lists, one per call (as 0/1 indicators of `shape`)."""
+    it = iter(lists)
+
+    def select_mb(size, _it=it):
+        m = np.zeros(int(np.prod(shape)), int)
+        m[next(_it)] = 1
+        return m.reshape(shape)
+    p.select_mb = select_mb
+
+
 @pytest.mark.parametrize('variant', ['svrg', 'reference'])
 def test_engine_matches_dropin_loop(variant):
     import algorithms
-    import problems
     import denoisers
     from oracle import loops as ol
     from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, TVProx
     B, n, mb, T2, eta, steps = 3, 64, 150, 4, 5e2, 9
     batch = CsmriBatch.synthetic(B, n, n, 0.2, 20.0, seed=5, dtype=torch.float64)
+    assert len(set(batch.M0.tolist())) > 1                    # Bernoulli masks: per-problem M0
     idx = batch.draw_minibatches(steps, mb, seed=2)
     eng = SvrgEngine(batch, TVProx(), eta, T2, mb, variant=variant)
     for s in range(steps):
@@ -23,24 +53,8 @@ def test_engine_matches_dropin_loop(variant):
     idx_h = idx.cpu().numpy()
     for b in range(B):
         # the same problem through the drop-in API: feed the engine's minibatches via select_mb
-        p = problems.CSMRI.__new__(problems.CSMRI)
-        problems.Problem.__init__(p, None, n, n, img=batch.xrec[b].cpu().numpy(), dtype=torch.float64)
-        p.pname, p.mask, p.M0, p.M = 'csmri', batch.mask_np[b].astype(int), int(batch.M0[b]), n * n
-        p.Xrec = batch.xrec[b].cpu().numpy()
-        p._xrec_d = batch.xrec[b:b + 1].clone()
-        p.Xinit = batch.xinit[b].cpu().numpy().ravel()
-        p.Y = None
-        p.plan = batch.plan.__class__(n, n, 1, torch.float64)
-        p._maskT = batch.maskT[b:b + 1].clone()
-        p._yh_full = batch.yh_full[b:b + 1].clone()
-        p._selT = torch.empty_like(p._maskT)
-        draws = iter(idx_h[:, b])
-
-        def select_mb(size, _d=draws):
-            m = np.zeros(n * n, int)
-            m[next(_d)] = 1
-            return m.reshape(n, n)
-        p.select_mb = select_mb
+        p = dropin_csmri(batch, b)
+        feed_minibatches(p, idx_h[:, b], (n, n))
         n_outer = -(-steps // T2)
         r = algorithms.pnp_svrg(p, denoisers.TVDenoiser(), eta, 2 + 3 * n_outer + 5 * steps - 1, T2, mb, verbose=False,
                                 converge_check=False, clock=ol.CountingClock(), variant=variant)
@@ -50,6 +64,69 @@ def test_engine_matches_dropin_loop(variant):
         assert len(inner) == steps
         assert np.abs(np.array(inner) - trace[:, b]).max() <= 1e-9
         np.testing.assert_allclose(r['z'], eng.z[b].cpu().numpy().ravel(), rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize('algo', ['gd', 'sgd', 'sarah', 'saga'])
+def test_other_engines_match_dropin_loops(algo):
+    """GdEngine / SgdEngine / SarahEngine / SagaEngine over a CsmriBatch (Bernoulli masks, float64) walk the
+    trajectories of the golden-pinned drop-in loops pnp_gd / pnp_sgd / pnp_sarah / pnp_saga fed the same minibatches
+    (and the same replaced-row stream for SAGA): identical rounded PSNR logs, iterates to 1e-10."""
+    import algorithms
+    import denoisers
+    from oracle import loops as ol
+    from pnp_svrg_amd.engine import CsmriBatch, TVProx, make_engine
+    B, n, mb, T2, eta, steps, hist, decay = 3, 64, 150, 4, 5e2, 10, 5, 0.95
+    batch = CsmriBatch.synthetic(B, n, n, 0.25, 20.0, seed=8, dtype=torch.float64)
+    idx = batch.draw_minibatches(steps + 1, mb, seed=3)
+    idx_h = idx.cpu().numpy()
+    np.random.seed(77)
+    rs = [np.random.choice(hist, 1).item() for _ in range(steps)]
+    if algo == 'saga':
+        eng = make_engine(batch, TVProx(), eta, T2, mb, lr_decay=decay, algorithm='saga', hist_size=hist, idx0=idx[0])
+        for s in range(steps):
+            eng.step(idx[s + 1], r=rs[s])
+    else:
+        eng = make_engine(batch, TVProx(), eta, T2, mb, lr_decay=decay, algorithm=algo)
+        for s in range(steps):
+            eng.step() if algo == 'gd' else eng.step(idx[s])
+    trace = eng.psnr_trace()
+    for b in range(B):
+        p = dropin_csmri(batch, b)
+        d = denoisers.TVDenoiser()
+        kw = dict(verbose=False, converge_check=False, clock=ol.CountingClock(), lr_decay=decay)
+        if algo == 'gd':
+            r = algorithms.pnp_gd(p, d, eta, 6 * steps - 3, **kw)
+            got = np.array(r['psnr_per_iter'])[1:]
+        elif algo == 'sgd':
+            feed_minibatches(p, idx_h[:, b], (n, n))
+            r = algorithms.pnp_sgd(p, d, eta, 5 * steps - 2, mb, **kw)
+            got = np.array(r['psnr_per_iter'])[1:]
+        elif algo == 'saga':
+            feed_minibatches(p, idx_h[:, b], (n, n))
+            np.random.seed(77)
+            r = algorithms.pnp_saga(p, d, eta, 5 * steps - 1, mb, hist_size=hist, **kw)
+            got = np.array(r['psnr_per_iter'])[1:]
+        else:
+            feed_minibatches(p, idx_h[:, b], (n, n))
+            o, j = (steps - 1) // T2, (steps - 1) % T2
+            r = algorithms.pnp_sarah(p, d, eta, 1 + o * (5 + 5 * T2) + 5 + 5 * j + 1, T2, mb, **kw)
+            got = np.array(r['psnr_per_iter'])                  # outer prox entries included, like the engine's log
+        assert len(got) == trace.shape[0], (len(got), trace.shape)
+        assert np.abs(got - trace[:, b]).max() <= 1e-9, (algo, got, trace[:, b])
+        np.testing.assert_allclose(r['z'], eng.z[b].cpu().numpy().ravel(), rtol=0, atol=1e-10)
+
+
+def test_log_ring_is_chronological():
+    """More prox evaluations than log rows: psnr_trace() returns the LAST n_log of them in order (trace[-1] is the
+    latest step)."""
+    from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, TVProx
+    batch = CsmriBatch.synthetic(2, 64, 64, 0.2, 20.0, seed=5)
+    big = SvrgEngine(batch, TVProx(), 5e2, 3, 100, seed=3)
+    small = SvrgEngine(batch, TVProx(), 5e2, 3, 100, seed=3, n_log=4)
+    for _ in range(7):
+        big.step()
+        small.step()
+    assert np.array_equal(small.psnr_trace(), big.psnr_trace()[-4:])
 
 
 def test_bench_line_smoke():
@@ -65,7 +142,47 @@ def test_bench_line_smoke():
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in line
-    assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1
+    rf = line['roofline']
+    assert rf['bound'] == 'mfma' and 0 < rf['frac'] < 1
+    # frac is EXECUTED matrix-core work over the peak; the algorithmic rate is reported beside it
+    assert rf['winograd_reduction'] == 1.5
+    assert abs(rf['algorithmic_tflops'] / rf['achieved'] - 1.5) < 0.01
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+
+
+def test_bench_default_line_has_secondary_configs():
+    """The default configuration (B = 120) carries configs 2 and 4 as `secondary` with their own rooflines, and the
+    headline `frac` stays a fraction at the default batch."""
+    import json
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert 0 < line['roofline']['frac'] < 1 and line['config']['batch_per_gpu'] == 120
+    sec = line['secondary']
+    assert sec['tv']['roofline']['bound'] == 'hbm' and 0 < sec['tv']['roofline']['frac'] < 1
+    assert sec['saga-nlm']['roofline']['bound'] == 'valu' and sec['saga-nlm']['value'] > 0
+    assert sec['saga-nlm']['roofline']['saga_table_update']['bound'] == 'hbm'
+    assert sec['tv']['psnr_db']['after_timed_steps_mean'] > sec['tv']['psnr_db']['initial_mean']
+
+
+def _mix64(x):
+    with np.errstate(over='ignore'):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def _mb_keys_np(seed, step, prob, pos):
+    """NumPy restatement of the draw's counter-based key (csrc/draw.h: fields absorbed one at a time)."""
+    with np.errstate(over='ignore'):
+        st = _mix64(_mix64(_mix64(np.uint64(seed)) + np.uint64(step)) + np.uint64(prob))
+        return (_mix64(st + pos.astype(np.uint64)) >> np.uint64(32)).astype(np.uint32)
 
 
 def test_device_minibatch_draw():
@@ -74,63 +191,82 @@ def test_device_minibatch_draw():
     from pnp_svrg_amd.engine import CsmriBatch
     B, n, mb = 4, 64, 100
     batch = CsmriBatch.synthetic(B, n, n, 0.2, 20.0, seed=9)
-    M0 = int(batch.M0[0])
-    sel = batch.plan.draw_minibatch(batch.mask_idx, mb, seed=7, step=3)
+    sel = batch.plan.draw_minibatch(batch.bits, mb, seed=7, step=3)
     s = sel.cpu().numpy()                                     # [B][W][H] transposed
     assert s.dtype == np.uint8 and set(np.unique(s)) <= {0, 1}
     assert (s.reshape(B, -1).sum(1) == mb).all()
     maskT = batch.maskT.cpu().numpy()
     assert (s <= maskT).all()
-    assert torch.equal(sel, batch.plan.draw_minibatch(batch.mask_idx, mb, seed=7, step=3))
-    assert not torch.equal(sel, batch.plan.draw_minibatch(batch.mask_idx, mb, seed=7, step=4))
+    assert torch.equal(sel, batch.plan.draw_minibatch(batch.bits, mb, seed=7, step=3))
+    assert not torch.equal(sel, batch.plan.draw_minibatch(batch.bits, mb, seed=7, step=4))
     assert not np.array_equal(s[0], s[1])
-    # uniformity: 400 draws, per-location frequency ~ Binomial(400, mb/M0)
+    # uniformity: 400 draws, per-location frequency ~ Binomial(400, mb/M0_b)
     cnt = np.zeros((B, n, n), np.int64)
     T = 400
     for t in range(T):
-        cnt += batch.plan.draw_minibatch(batch.mask_idx, mb, seed=11, step=t).cpu().numpy()
-    p = mb / M0
-    f = cnt[maskT == 1] / T
-    assert abs(f.mean() - p) < 1e-12 + 1e-9                   # exactly mb per draw
-    z = (f - p) / np.sqrt(p * (1 - p) / T)
-    assert np.abs(z).max() < 5.5 and abs(z.std() - 1.0) < 0.1
-    # edge: mb == M0 selects the whole mask; mb == 1 selects one location
-    full = batch.plan.draw_minibatch(batch.mask_idx, M0, seed=1, step=0)
-    assert torch.equal(full, batch.maskT)
-    one = batch.plan.draw_minibatch(batch.mask_idx, 1, seed=1, step=0)
+        cnt += batch.plan.draw_minibatch(batch.bits, mb, seed=11, step=t).cpu().numpy()
+    for b in range(B):
+        p = mb / batch.M0[b]
+        f = cnt[b][maskT[b] == 1] / T
+        assert abs(f.mean() - p) < 1e-9                       # exactly mb per draw
+        z = (f - p) / np.sqrt(p * (1 - p) / T)
+        assert np.abs(z).max() < 5.5 and abs(z.std() - 1.0) < 0.15
+    # edge: mb >= M0 selects the whole mask; mb == 1 selects one location
+    full = batch.plan.draw_minibatch(batch.bits, int(batch.M0.max()), seed=1, step=0)
+    assert torch.equal(full[int(np.argmax(batch.M0))], batch.maskT[int(np.argmax(batch.M0))])
+    assert torch.equal(batch.plan.draw_minibatch(batch.bits, n * n, seed=1, step=0), batch.maskT)
+    one = batch.plan.draw_minibatch(batch.bits, 1, seed=1, step=0)
     assert (one.reshape(B, -1).sum(1) == 1).all()
 
 
-def _mb_hash_np(seed, step, prob, j):
-    """NumPy restatement of the draw's counter-based key (csmri.hip mb_hash: splitmix64 finaliser, high 32 bits)."""
-    with np.errstate(over='ignore'):
-        x = np.uint64(seed) ^ (np.uint64(step) << np.uint64(40)) ^ (np.uint64(prob) << np.uint64(20)) ^ j.astype(np.uint64)
-        x = x + np.uint64(0x9E3779B97F4A7C15)
-        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        x = x ^ (x >> np.uint64(31))
-    return (x >> np.uint64(32)).astype(np.uint32)
-
-
-@pytest.mark.parametrize('n,frac', [(64, 0.3), (256, 0.2), (256, 0.7)])
+@pytest.mark.parametrize('n,frac', [(64, 0.3), (128, 0.5), (256, 0.2), (256, 0.7)])
 def test_device_minibatch_draw_known_answer(n, frac):
-    """The draw is exactly "the mb smallest hash keys, ties by position" -- recomputed on the host.  256 x 256 at
-    70 % sampling (M0 = 45 875 keys) exceeds the LDS key cache and takes the re-hashing build of the kernel; the
-    other cases take the cached build."""
+    """The draw is exactly "the mb smallest (key, position) pairs" -- recomputed on the host from the published key
+    construction (include/pnp_hip.h).  Problems of one call have different M0."""
     from pnp_svrg_amd import ops
     B, mb, seed, step = 3, 777, 0xDEADBEEFCAFE, 12345
     rng = np.random.default_rng(n)
-    M0 = int(round(frac * n * n))
-    idx = np.stack([np.sort(rng.choice(n * n, M0, replace=False)) for _ in range(B)]).astype(np.int32)
     plan = ops.CsmriPlan(n, n, B, torch.float32)
-    sel = plan.draw_minibatch(torch.from_numpy(idx).cuda(), mb, seed=seed, step=step).cpu().numpy()
-    for b in range(B):
-        keys = _mb_hash_np(seed, step, b, np.arange(M0))
-        order = np.lexsort((np.arange(M0), keys))[:mb]
-        want = np.zeros((n, n), np.uint8)
-        i = idx[b][order]
-        want[i % n, i // n] = 1                                   # transposed selector [W][H]
-        assert np.array_equal(sel[b], want)
+    mask = (rng.random((B, n, n)) < np.array([frac, 0.8 * frac, 1.2 * frac])[:, None, None]).astype(np.uint8)
+    bits = plan.pack_mask(plan.sel_from_dense(torch.from_numpy(mask).cuda()))
+    mbd = plan.draw_thresholds(bits, mb, seed, step, nsteps=2)
+    for t in range(2):
+        sel = plan.sel_from_thresholds(bits, mbd[t]).cpu().numpy()
+        for b in range(B):
+            pos = np.flatnonzero(mask[b])                         # flat row-major positions, ascending
+            keys = _mb_keys_np(seed, step + t, b, pos)
+            order = np.lexsort((pos, keys))[:mb]
+            want = np.zeros(n * n, np.uint8)
+            want[pos[order]] = 1
+            assert np.array_equal(sel[b], want.reshape(n, n).T)   # transposed selector [W][H]
+            T, P = keys[order[-1]], pos[order[-1]]
+            d = mbd[t, b].cpu().numpy().view(np.uint32)           # {state lo, state hi, T, P}
+            assert (int(d[2]), int(d[3])) == (int(T), int(P))
+
+
+def test_device_draw_seeds_are_independent():
+    """streams of different seeds / problems must be unrelated.  Two problems with the SAME mask: the
+    seed-0 and seed-1 minibatches overlap like independent draws (~ mb^2 / M0, hypergeometric), and the field
+    boundaries do not alias: (seed = 2^20, problem 0) != (seed = 0, problem 1), (step = 2^24 + 1) != (step = 1)."""
+    from pnp_svrg_amd import ops
+    n, mb = 256, 1000
+    rng = np.random.default_rng(0)
+    m = (rng.random((n, n)) < 0.2).astype(np.uint8)
+    mask = np.stack([m, m])
+    plan = ops.CsmriPlan(n, n, 2, torch.float32)
+    bits = plan.pack_mask(plan.sel_from_dense(torch.from_numpy(mask).cuda()))
+    M0 = int(m.sum())
+    draw = lambda seed, step: plan.draw_minibatch(bits, mb, seed=seed, step=step).cpu().numpy().astype(np.int64)
+    a, b = draw(0, 5), draw(1, 5)
+    mean, sd = mb * mb / M0, np.sqrt(mb * (mb / M0) * (1 - mb / M0) * (M0 - mb) / (M0 - 1))
+    for p in range(2):
+        ov = int((a[p] * b[p]).sum())
+        assert abs(ov - mean) < 6 * sd, (ov, mean, sd)            # the old XOR construction gave a permuted copy
+    ov01 = int((a[0] * a[1]).sum())                               # same seed, same mask, different problem
+    assert abs(ov01 - mean) < 6 * sd
+    c = draw(2 ** 20, 5)
+    assert not np.array_equal(c[0], a[1])
+    assert not np.array_equal(draw(0, 2 ** 24 + 1)[0], draw(0, 1)[0])
 
 
 def test_sweep_runner_single_process():
@@ -232,41 +368,3 @@ def test_graph_replay_equals_eager(prox_kind):
         e1.step()
     torch.cuda.synchronize(); te = time.perf_counter() - t0
     print(f'[{prox_kind}] B={B} {n}x{n}: eager {te / (20 * T2) * 1e6:.1f} us/step, graph {tg / (20 * T2) * 1e6:.1f} us/step')
-
-
-@pytest.mark.parametrize('n,host_idx', [(64, False), (64, True), (256, False)])
-def test_fused_tv_engine_equals_plain_engine(n, host_idx):
-    """SvrgEngineFusedTV (transposed storage, gradient step + noise estimate + prox + error in one kernel) walks the
-    same trajectory as SvrgEngine: same minibatches (device draws or host index lists), iterates equal to ~1e-5,
-    PSNR logs within 0.01 dB, eager and hipGraph forms."""
-    from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, SvrgEngineFusedTV, TVProx, make_engine
-    B, mb, T2, steps = 3, 150, 5, 15
-    batch = CsmriBatch.synthetic(B, n, n, 0.2, 20.0, seed=21)
-    plain = SvrgEngine(batch, TVProx(sigma_modifier=1.2), 5e2, T2, mb, seed=4)
-    fused = make_engine(batch, TVProx(sigma_modifier=1.2), 5e2, T2, mb, seed=4, fused=True)
-    assert isinstance(fused, SvrgEngineFusedTV)
-    assert type(make_engine(batch, TVProx(), 5e2, T2, mb)) is SvrgEngine        # opt-in only (measured slower)
-    assert torch.equal(fused.z, batch.xinit)
-    idx = batch.draw_minibatches(steps, mb, seed=2) if host_idx else None
-    for s in range(steps):
-        plain.step(None if idx is None else idx[s])
-        fused.step(None if idx is None else idx[s])
-    assert torch.equal(plain.selT, fused.selT.transpose(1, 2))          # the same minibatch, transposed problem
-    d = (plain.z - fused.z).abs().max().item()
-    assert d <= 2e-5, d
-    assert np.abs(plain.psnr_trace() - fused.psnr_trace()).max() <= 0.01 + 1e-9
-    assert plain.psnr_trace()[-1].mean() > plain.psnr_trace()[0].mean()
-    assert fused.prox.t == plain.prox.t == steps
-    # hipGraph form of the fused engine == its eager form
-    g = make_engine(batch, TVProx(sigma_modifier=1.2), 5e2, T2, mb, seed=4, fused=True)
-    g.capture()
-    assert torch.equal(g.z, batch.xinit)
-    g.run_outer(steps // T2)
-    if idx is None:
-        assert torch.equal(g.z.contiguous(), fused.z.contiguous())
-        assert np.array_equal(g.psnr_trace(), fused.psnr_trace())
-    # not eligible -> the plain engine
-    b64 = CsmriBatch.synthetic(2, 64, 64, 0.2, 20.0, seed=1, dtype=torch.float64)
-    assert type(make_engine(b64, TVProx(), 5e2, T2, mb)) is SvrgEngine
-    with pytest.raises(ValueError):
-        make_engine(b64, TVProx(), 5e2, T2, mb, fused=True)

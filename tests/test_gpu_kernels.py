@@ -158,45 +158,84 @@ def test_minmax_axpby(ops):
     np.testing.assert_allclose(r.cpu().numpy(), 2.25 * x - 0.5 * y.cpu().numpy(), atol=1e-14)
 
 
-@pytest.mark.parametrize('n', [64, 256])
-def test_fused_grad_prox_tv_equals_two_kernels(ops, n):
-    """pnp_csmri_grad_prox_tv (one pass: SVRG step -> noise estimate -> Haar BayesShrink along the storage rows ->
-    squared error) == pnp_csmri_grad followed by pnp_prox_tv on the transposed arrays.  The noise estimate is
-    bit-identical (same products, exact median); the shrink differs only by the summation order of the sub-band
-    energies."""
+@pytest.mark.parametrize('n,dt', [(64, torch.float64), (128, torch.float64), (256, torch.float64), (256, torch.float32)])
+def test_selector_forms_agree(ops, n, dt):
+    """The three selector forms of the column pass give the same gradient: explicit uint8 selector, bit-packed mask,
+    and mask o device-drawn minibatch re-derived from its threshold descriptor (== the materialised selector).  The
+    data term formed inside the column pass from YT == the pre-packed one (pnp_csmri_pack_y).  Per-problem alpha_vec
+    == per-problem scaling afterwards."""
     rng = np.random.default_rng(n)
     B = 3
-    plan = ops.CsmriPlan(n, n, B, torch.float32)
-    p = np.pad(rng.random((B, n, n)), ((0, 0), (2, 2), (2, 2)), mode='wrap')
-    smooth = sum(p[:, i:i + n, j:j + n] for i in range(5) for j in range(5)) / 25.0
-    xrec = dev(smooth, torch.float32)
-    z = dev(smooth + 0.05 * rng.standard_normal((B, n, n)), torch.float32)
-    w = dev(smooth + 0.05 * rng.standard_normal((B, n, n)), torch.float32)
-    mu = dev(1e-4 * rng.standard_normal((B, n, n)), torch.float32)
-    sel = dev((rng.random((B, n, n)) < 0.03).astype(np.uint8))
-    lr, mb = 1e3, 120.0
-    kw = dict(b=w, alpha=-lr / mb, beta=1.0, c1=z, gamma=-lr, c2=mu)
-    stepped = plan.grad(z, sel, **kw)
-    T = lambda a: a.transpose(1, 2).contiguous()
-    want, want_sse, want_sig = ops.prox_tv(T(stepped), xrec=T(xrec), sigma_modifier=1.3)
-    got, sse, sig = plan.grad_prox_tv(z, sel, xrec=xrec, sigma_modifier=1.3, **kw)
-    assert torch.equal(sig, want_sig)                                   # identical noise estimate
-    assert float(sig.min()) > 0
-    d = (got - T(want)).abs().max().item()
-    assert d <= 2e-6, d
-    assert not torch.equal(got, stepped)                                # the prox did something
-    np.testing.assert_allclose(sse.cpu().numpy(), want_sse.cpu().numpy(), rtol=1e-5)
-    # in place (out aliases a and c1, as the engine calls it) and without the error sum
-    z2 = z.clone()
-    plan.grad_prox_tv(z2, sel, b=w, alpha=-lr / mb, beta=1.0, c1=z2, gamma=-lr, c2=mu, out=z2, sigma_modifier=1.3)
-    assert torch.equal(z2, got)
-    # sigma == 0 -> fallback threshold path (constant image: every detail coefficient is zero -> NaN estimate
-    # is NOT > 0, fallback_sigma is used, exactly like the two-kernel path)
-    c = torch.full((B, n, n), 0.25, dtype=torch.float32, device='cuda')
-    zero_sel = torch.zeros_like(sel)
-    a1, _, s1 = plan.grad_prox_tv(c, zero_sel, alpha=1.0, beta=1.0, c1=c, fallback_sigma=0.1)
-    b1, _, s2 = ops.prox_tv(T(plan.grad(c, zero_sel, alpha=1.0, beta=1.0, c1=c)), fallback_sigma=0.1)
-    assert torch.equal(torch.isnan(s1), torch.isnan(s2))
-    assert torch.equal(torch.isnan(a1), torch.isnan(T(b1)))
-    m = ~torch.isnan(a1)
-    assert (a1[m] - T(b1)[m]).abs().max().item() <= 2e-6 if m.any() else True
+    cdt = torch.complex128 if dt == torch.float64 else torch.complex64
+    tol = 1e-12 if dt == torch.float64 else 2e-5
+    plan = ops.CsmriPlan(n, n, B, dt)
+    mask = (rng.random((B, n, n)) < np.array([0.2, 0.35, 0.6])[:, None, None]).astype(np.uint8)      # different M0 per problem
+    maskT = plan.sel_from_dense(dev(mask))
+    bits = plan.pack_mask(maskT)
+    # pack_mask against NumPy
+    want = np.packbits(np.swapaxes(mask, 1, 2).reshape(B, n, n // 32, 32), axis=-1, bitorder='little').view(np.uint32).reshape(B, n, n // 32)
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), want)
+    z = dev(rng.standard_normal((B, n, n)), dt)
+    Y = rng.standard_normal((B, n, n)) + 1j * rng.standard_normal((B, n, n))
+    YT = torch.from_numpy(np.ascontiguousarray(np.swapaxes(Y, 1, 2))).to('cuda', cdt).contiguous()
+    yh = plan.pack_y(YT, maskT)
+    g_u8 = plan.grad(z, maskT, yh=yh)
+    g_bits = plan.grad(z, bits=bits, yh=yh)
+    assert torch.equal(g_u8, g_bits)
+    g_yt = plan.grad(z, bits=bits, YT=YT)
+    assert (g_yt - g_u8).abs().max().item() <= tol * max(1.0, g_u8.abs().max().item())
+    # per-problem scale
+    av = dev(np.array([0.5, 2.0, -3.0]), dt)
+    g_av = plan.grad(z, bits=bits, yh=yh, alpha=0.25, alpha_vec=av)
+    assert (g_av - 0.25 * av[:, None, None] * g_u8).abs().max().item() <= tol * max(1.0, g_u8.abs().max().item())
+    # hashed minibatch == its materialised selector, with and without the data term
+    mb = 150
+    mbd = plan.draw_thresholds(bits, mb, seed=11, step0=5, nsteps=3)
+    for j in range(3):
+        selT = plan.sel_from_thresholds(bits, mbd[j])
+        s = selT.cpu().numpy()
+        assert (s.reshape(B, -1).sum(1) == mb).all() and (s <= maskT.cpu().numpy()).all()
+        w = dev(rng.standard_normal((B, n, n)), dt)
+        a1 = plan.grad(z, selT, b=w, alpha=0.3, beta=1.0, c1=z)
+        a2 = plan.grad(z, bits=bits, mbd=mbd[j], b=w, alpha=0.3, beta=1.0, c1=z)
+        assert torch.equal(a1, a2)
+        b1 = plan.grad(z, selT, YT=YT)
+        b2 = plan.grad(z, bits=bits, mbd=mbd[j], YT=YT)
+        assert torch.equal(b1, b2)
+        b3 = plan.grad(z, selT, yh=plan.pack_y(YT, selT))
+        assert (b1 - b3).abs().max().item() <= tol * max(1.0, b3.abs().max().item())
+
+
+def test_saga_table_update_and_generic_draws(ops):
+    """pnp_saga_table_update == its five NumPy lines (incl. prev aliasing the replaced row); generic draws over M
+    measurements: exactly mb members, indicator == ascending row list, deterministic, different per step / problem."""
+    rng = np.random.default_rng(3)
+    n = 5000
+    for dt in (torch.float64, torch.float32):
+        z, g, slot, prev, ts = (rng.standard_normal(n) for _ in range(5))
+        zd, gd, sd, pd, td = (dev(v, dt) for v in (z, g, slot, prev, ts))
+        ops.saga_table_update(zd, gd, sd, pd, td, 0.7, 0.25)
+        s2 = ts + g - slot
+        tol = 1e-14 if dt == torch.float64 else 2e-6
+        np.testing.assert_allclose(zd.cpu().numpy(), z - 0.7 * ((g - prev) + s2 * 0.25), atol=tol * 10)
+        np.testing.assert_allclose(td.cpu().numpy(), s2, atol=tol * 10)
+        assert torch.equal(sd, gd)
+        # prev is the row being replaced
+        zd, gd, sd, td = (dev(v, dt) for v in (z, g, slot, ts))
+        ops.saga_table_update(zd, gd, sd, sd, td, 0.7, 0.25)
+        np.testing.assert_allclose(zd.cpu().numpy(), z - 0.7 * ((g - slot) + s2 * 0.25), atol=tol * 10)
+    M, B, mb = 4097, 4, 333
+    mbd = ops.draw_thresholds(M, B, mb, seed=5, step0=2, nsteps=2)
+    sel = ops.indicator_from_thresholds(M, mbd[0]).cpu().numpy()
+    assert (sel.sum(1) == mb).all()
+    rows = ops.rows_from_thresholds(M, mb, mbd[0]).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(rows[b], np.flatnonzero(sel[b]))
+    assert torch.equal(mbd, ops.draw_thresholds(M, B, mb, seed=5, step0=2, nsteps=2))
+    sel1 = ops.indicator_from_thresholds(M, mbd[1]).cpu().numpy()
+    assert not np.array_equal(sel, sel1) and not np.array_equal(sel[0], sel[1])
+    assert torch.equal(mbd[1], ops.draw_thresholds(M, B, mb, seed=5, step0=3, nsteps=1)[0])       # step0 + slot == step
+    full = ops.indicator_from_thresholds(M, ops.draw_thresholds(M, B, M, seed=1, step0=0)[0]).cpu().numpy()
+    assert full.all()
+    idx = torch.from_numpy(rows.astype(np.int32)).cuda()
+    assert np.array_equal(ops.indicator_from_indices(idx, M).cpu().numpy(), sel)

@@ -18,13 +18,18 @@ def test_grad_stoch_all_ones_equals_grad_full(batch):
     """grad_stoch(x, all-ones)/M0 == grad_full(x) for CSMRI."""
     p = batch.plan
     x = torch.rand(8, 256, 256, dtype=torch.float64, device='cuda')
-    gf = p.grad(x, batch.maskT, yh=batch.yh_full, alpha=1.0 / float(batch.M0[0]))
+    gf = p.grad(x, batch.maskT, yh=batch.yh_full, alpha_vec=batch.inv_m0)
     # the selector mask o ones is the mask itself, rebuilt from index lists
-    idx = torch.from_numpy(np.stack([np.flatnonzero(m) for m in batch.mask_np]).astype(np.int32)).cuda()
-    sel = p.sel_from_indices(idx)
+    # (Bernoulli masks: a different number of sampled points per problem -> padded index lists, -1 = no entry)
+    lists = [np.flatnonzero(m) for m in batch.mask_np]
+    idx = np.full((len(lists), max(len(l) for l in lists)), -1, np.int32)
+    for i, l in enumerate(lists):
+        idx[i, :len(l)] = l
+    sel = p.sel_from_indices(torch.from_numpy(idx).cuda())
     assert torch.equal(sel, batch.maskT)
     gs = p.grad(x, sel, yh=batch.yh_full)
-    assert (gs / float(batch.M0[0]) - gf).abs().max().item() < 1e-15
+    assert (gs * batch.inv_m0[:, None, None] - gf).abs().max().item() < 1e-15
+    assert len(set(batch.M0.tolist())) > 1
 
 
 def test_f13_difference_identity_and_linearity(batch):

@@ -248,3 +248,71 @@ def test_mmo_oracle():
         assert y.dtype == np.float32 and y.shape == g[f'{name}_out'].shape
         assert np.abs(y - g[f'{name}_out']).max() <= 2e-6
     assert den.t == 2
+
+
+# ---------------------------------------------------------------------------------- round-2 fixtures (make_golden_r2.py)
+def _png(tmp_path, name, pixels):
+    from PIL import Image
+    path = str(tmp_path / name)
+    Image.fromarray(pixels).save(path)
+    return path
+
+
+def test_resize_and_kernel_png(g_r2, tmp_path):
+    """a6: PIL's bicubic 512^2 -> 256^2 resize + min-max of the reference's data/Set12/08.png pixels; a13: the
+    kernel_path branch (kernel.png resized to H x W, / N) at 64^2 and 256^2."""
+    g = g_r2
+    src = _png(tmp_path, '08.png', g['resize_pixels'])
+    p = op.Problem(src, 256, 256)
+    assert np.array_equal(p.Xrec, g['resize_Xrec'])
+    kp = _png(tmp_path, 'kernel.png', g['kernelpng_pixels'])
+    np.random.seed(0)
+    p64 = op.Deblur(IMG64, H=64, W=64, kernel_path=kp, scale_percent=100, snr=20.)
+    assert np.array_equal(p64.B, g['kernelpng_B64'])
+    np.random.seed(0)
+    p = op.Deblur(IMG256, H=256, W=256, kernel_path=kp, scale_percent=100, snr=20.)
+    assert np.array_equal(p.B, g['kernelpng_B256'])
+    assert p.sigma == pytest.approx(float(g['kernelpng_sigma256']), rel=1e-13)
+    np.testing.assert_allclose(p.Y, g['kernelpng_Y256'], rtol=1e-12, atol=1e-15)
+    np.testing.assert_array_equal(p.Xinit, g['kernelpng_Xinit256'])
+    gf = g['kernelpng_grad_full256']
+    assert np.abs(p.grad_full(p.Xinit) - gf).max() <= 1e-11 * np.abs(gf).max()
+
+
+def test_nlm_256(g_r2, g_denoise):
+    """a19 at BASELINE's size: NLMDenoiser.denoise on a 256 x 256 iterate, bit-exact."""
+    d = od.NLMDenoiser()
+    d.sigma = 1.0
+    s = od.estimate_sigma(g_denoise['r256_z0'])
+    assert s == float(g_r2['nlm256_sigma_est'])
+    assert np.array_equal(d.denoise(noisy=g_denoise['r256_z0'], sigma_est=s), g_r2['nlm256_out'])
+
+
+def test_config4_full_size(g_r2):
+    """BASELINE config 4 at 256 x 256: Deblur ("Minimal") gradients and the pnp_saga + NLM trace of the reference."""
+    g = g_r2
+    np.random.seed(0)
+    p = op.Deblur(IMG256, H=256, W=256, kernel='Minimal', scale_percent=100, snr=20.)
+    assert p.sigma == pytest.approx(float(g['c4_sigma']), rel=1e-13)
+    np.testing.assert_allclose(p.Y, g['c4_Y'], rtol=0, atol=1e-15)
+    np.random.seed(3)
+    mb = p.select_mb(3000)
+    assert np.array_equal(mb, g['c4_mb'])
+    for got, key in ((p.grad_full(p.Xinit), 'c4_grad_full'), (p.grad_stoch(p.Xinit, mb), 'c4_grad_stoch')):
+        assert np.abs(got - g[key]).max() <= 1e-11 * np.abs(g[key]).max()
+    np.random.seed(1)
+    d = od.NLMDenoiser()
+    d.sigma = 1.0
+    r = ol.pnp_saga(p, d, 1e9, 5 * 6 - 1, 3000, hist_size=4, converge_check=False, clock=ol.CountingClock())
+    assert list(r['psnr_per_iter']) == list(g['c4_saga_nlm_psnr'])
+    np.testing.assert_allclose(r['z'], g['c4_saga_nlm_z'], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('sigma', [5, 40])
+def test_dncnn_other_noise_levels(sigma, g_denoise):
+    """a20 at the other noise levels the reference ships weights for: wrapper outputs of the reference class."""
+    g = golden(f'dncnn_noise{sigma}.npz')
+    w = {k: g[k] for k in g.files if k.startswith(('conv', 'bn')) or k == 'n_layers'}
+    d = od.DnCNNDenoiser(w, sigma)
+    np.testing.assert_allclose(d.denoise(noisy=g_denoise['s64_z0']), g['den64'], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(d.denoise(noisy=g_denoise['r256_z0']), g['den256'], rtol=0, atol=5e-6)

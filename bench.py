@@ -38,7 +38,10 @@ H = W = 256
 SAMPLE_PROB, SNR = 0.2, 20.0
 ETA, T2, MB = 2e3, 10, 1000
 NET_SIGMA = 15
-SAGA_ETA, SAGA_MB, SAGA_HIST, SAGA_SNR = 3e8, 3000, 50, 20.0    # the reference's blur has gain 1/sqrt(N): gradients are O(1e-9)
+# the reference's blur has gain 1/sqrt(N) (B = kernel / N, fft_blur x sqrt(N)): gradients are O(1e-9) and a minibatch's
+# Lipschitz constant ~ 5e-9; with the reference's table initialisation (all 50 rows = the gradient at the U(0,1) start,
+# pnp_saga.py:29-31) the direction keeps that bias for ~hist steps, hence the small step size
+SAGA_ETA, SAGA_MB, SAGA_HIST, SAGA_SNR = 5e6, 3000, 50, 20.0
 FLOP_MID_PER_IMAGE = 2 * 9 * 64 * 64 * H * W          # one 64->64 3x3 conv layer, direct form
 WINOGRAD_REDUCTION = 1.5                               # F(2,3) along x executes 2/3 of the direct form's multiply-adds
 F32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak

@@ -49,17 +49,22 @@ int pnp_csmri_pack_mask(pnp_csmri_plan* plan, const uint8_t* selT, uint32_t* bit
 
 /* Device-side minibatch draw (problems/CSMRI.py:66-74 semantics: `mb` of the problem's sampled locations, uniform
  * without replacement; problems of one batch may have different numbers of sampled locations).  Every sampled
- * location i (flat row-major k-space index, as np.flatnonzero(mask) counts) gets the 32-bit key
- *     key(i) = mix64(state + i) >> 32,  state = mix64(mix64(mix64(seed) + step) + problem),  mix64 = splitmix64
- * and the mb smallest (key, i) pairs win.  Only the threshold pair is computed: descriptor {uint64 state; uint32 T;
- * uint32 P} per (step, problem); i is in the minibatch iff key(i) < T or (key(i) == T and i <= P).  The gradient
- * (pnp_csmri_grad_sel) re-derives membership from it, so no selector is ever written.  mbd: [nsteps][batch]
- * descriptors (16 bytes each) for steps step0 .. step0 + nsteps - 1 -- a whole outer iteration in one launch.
+ * location i (flat row-major k-space index, as np.flatnonzero(mask) counts) gets a 32-bit key
+ *     state = mix64(mix64(mix64(seed) + step) + problem)                       (mix64 = splitmix64 finaliser)
+ *     x = lo32(state) ^ i;  x ^= x >> 16;  x *= 0x7feb352d;  x ^= x >> 15;  x *= 0x846ca68b;  x ^= x >> 16
+ *     key(i) = x ^ hi32(state)
+ * and the mb smallest (key, i) pairs win.  Outputs, for steps step0 .. step0 + nsteps - 1 (a whole outer iteration in
+ * one launch):
+ *   mbd     [nsteps][batch] descriptors {uint64 state; uint32 T; uint32 P} (16 bytes): i is in the minibatch iff
+ *           key(i) < T or (key(i) == T and i <= P);
+ *   selbits [nsteps][batch][W][H/32] uint32 (may be NULL): mask o minibatch in the bit-packed layout of bitsT, which
+ *           pnp_csmri_grad_sel takes as its selector -- 8 KiB per 256 x 256 problem-step instead of a 64 KiB byte
+ *           selector.
  * Deterministic in (seed, step); NOT NumPy's legacy stream (reference-identical draws come from the host).
  * step_dev (may be NULL): device-resident counter added to `step0`, so the call can be replayed from a hipGraph.
  * mb >= the number of sampled locations selects them all.                                                */
 int pnp_csmri_draw_thresholds(pnp_csmri_plan* plan, const uint32_t* bitsT, int mb, uint64_t seed, uint32_t step0,
-                              int nsteps, const uint32_t* step_dev, void* mbd, void* stream);
+                              int nsteps, const uint32_t* step_dev, void* mbd, uint32_t* selbits, void* stream);
 /* mask o minibatch of ONE step as an explicit transposed selector (mbd: [batch] descriptors of that step).   */
 int pnp_csmri_sel_from_thresholds(pnp_csmri_plan* plan, const uint32_t* bitsT, const void* mbd, uint8_t* selT,
                                   void* stream);
@@ -83,18 +88,31 @@ int pnp_csmri_grad(pnp_csmri_plan* plan, const void* a, const void* b, const uin
                    const void* yh, double alpha, double beta, const void* c1,
                    double gamma, const void* c2, void* out, void* stream);
 
-/* The same gradient with the other selector forms and a per-problem scale.  Exactly one of
- *   selT != NULL                   explicit transposed uint8 selector (as pnp_csmri_grad)
- *   bitsT != NULL, mbd == NULL     the bit-packed sampling mask itself (grad_full)
- *   bitsT != NULL, mbd != NULL     mask o device-drawn minibatch: mbd = this step's [batch] descriptors
+/* The same gradient with the other selector form and a per-problem scale.  Exactly one of
+ *   selT  != NULL     explicit transposed uint8 selector (as pnp_csmri_grad)
+ *   bitsT != NULL     bit-packed transposed selector [batch][W][H/32]: the sampling mask itself (grad_full), or one
+ *                     step's row of pnp_csmri_draw_thresholds' selbits (mask o device-drawn minibatch)
  * Data term: yh (packed for exactly this selector, pnp_csmri_pack_y) or YT ([batch][W][H] complex = Y transposed:
  * the selector's data term is then formed inside the column pass, which is what a minibatch selector that exists
- * only as a threshold needs -- grad_stoch of pnp_sgd.py:33 / pnp_saga.py:45); at most one of the two.
+ * drawn on the device needs -- grad_stoch of pnp_sgd.py:33 / pnp_saga.py:45); at most one of the two.
  * alpha_vec (may be NULL): [batch] values of `dtype`; problem b uses alpha * alpha_vec[b] -- the 1/M0 of
  * problems/CSMRI.py:81 when the masks of a batch have different counts (Bernoulli masks, CSMRI.py:43-45).    */
 int pnp_csmri_grad_sel(pnp_csmri_plan* plan, const void* a, const void* b, const uint8_t* selT, const uint32_t* bitsT,
-                       const void* mbd, const void* yh, const void* YT, double alpha, const void* alpha_vec, double beta,
+                       const void* yh, const void* YT, double alpha, const void* alpha_vec, double beta,
                        const void* c1, double gamma, const void* c2, void* out, void* stream);
+
+/* One WHOLE inner iteration of pnp_svrg with the TV prox (algorithms/pnp_svrg.py:52-80: minibatch SVRG direction, step,
+ * estimate_sigma, TVDenoiser.denoise, Problem.PSNR) in one kernel, one workgroup per problem, the image register-
+ * resident from the first load to the last store (f32 plans of 256 x 256):
+ *     out = prox_TV( alpha * alpha_vec[b] * Re ifft2( sel o fft2(a - b) ) + beta * c1 + gamma * c2 )
+ * bitsT: bit-packed selector as in pnp_csmri_grad_sel (one step's row of pnp_csmri_draw_thresholds' selbits; no data
+ * term: the Y terms of the SVRG difference cancel).  sigma_modifier, fallback_sigma, xrec, sse_out, sigma_out as in
+ * pnp_prox_tv (the noise estimate is always made in-kernel).  denoise == 0: stop after the noise estimate and store the
+ * stepped image (for a prox that is not this one).  out may alias a, c1 or c2.                              */
+int pnp_csmri_svrg_step(pnp_csmri_plan* plan, const void* a, const void* b, const uint32_t* bitsT, double alpha,
+                        const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
+                        int denoise, double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out,
+                        void* sigma_out, void* stream);
 
 /* ------------------------------------------------------------------ Deblur / super-resolution
  * Replaces problems/DeblurSR.py:119-147: 1-D circular blur of the raveled image via a length-H*W FFT

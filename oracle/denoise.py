@@ -118,8 +118,12 @@ def fast_exp(y):
     """skimage fast_exp.h: high int32 word = (int32)(2^20/ln2 * y) + (1072693248-60801),
     low word 0, reinterpret as double.  Vectorised; C truncation toward zero."""
     y = np.asarray(y, dtype=np.float64)
-    hi = np.trunc(1512775.3951951856938 * y).astype(np.int64) + 1072632447
-    hi = ((hi + 2 ** 31) % 2 ** 32 - 2 ** 31).astype(np.int64)     # int32 wrap
+    prod = np.trunc(1512775.3951951856938 * y)
+    with np.errstate(invalid='ignore'):
+        # (int) of an out-of-range double is INT_MIN on x86 (cvttsd2si), which is what the compiled kernel does
+        prod = np.where(np.abs(prod) < 2.0 ** 31, prod, -2.0 ** 31)
+    hi = prod.astype(np.int64) + 1072632447
+    hi = ((hi + 2 ** 31) % 2 ** 32 - 2 ** 31).astype(np.int64)     # int32 wrap of the addition
     bits = (hi.astype(np.int64) << 32).astype(np.int64)
     return bits.view(np.float64)
 

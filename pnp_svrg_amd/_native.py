@@ -23,7 +23,7 @@ SIGNATURES = {
     'pnp_csmri_plan_destroy': (_i, [_vp]),
     'pnp_csmri_sel_from_indices': (_i, [_vp, _vp, _i, _vp, _vp]),
     'pnp_csmri_pack_mask': (_i, [_vp, _vp, _vp, _vp]),
-    'pnp_csmri_draw_thresholds': (_i, [_vp, _vp, _i, ctypes.c_uint64, ctypes.c_uint32, _i, _vp, _vp, _vp]),
+    'pnp_csmri_draw_thresholds': (_i, [_vp, _vp, _i, ctypes.c_uint64, ctypes.c_uint32, _i, _vp, _vp, _vp, _vp]),
     'pnp_csmri_sel_from_thresholds': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pnp_csmri_draw_minibatch': (_i, [_vp, _vp, _i, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, _vp]),
     'pnp_counter_add': (_i, [_vp, ctypes.c_uint32, _vp]),
@@ -31,7 +31,8 @@ SIGNATURES = {
     'pnp_csmri_sel_from_dense': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_csmri_pack_y': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pnp_csmri_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _d, _vp, _vp, _vp]),
-    'pnp_csmri_grad_sel': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _d, _vp, _vp, _vp]),
+    'pnp_csmri_grad_sel': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _d, _vp, _vp, _vp]),
+    'pnp_csmri_svrg_step': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _d, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp]),
     'pnp_deblur_plan_create': (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     'pnp_deblur_plan_destroy': (_i, [_vp]),
     'pnp_deblur_grad': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp]),

@@ -83,15 +83,14 @@ __global__ __launch_bounds__(256) void k_rows_fwd(const T* __restrict__ a, const
 // ------------------------------------------------------------------------------- columns
 // Selector forms of the column pass:
 //   SEL_U8   explicit transposed uint8 selector [W][H] (host-drawn minibatches: reference-identical index lists)
-//   SEL_BITS the sampling mask itself, bit-packed and transposed: word [kx][ky >> 5], bit ky & 31   (grad_full)
-//   SEL_HASH mask o device-drawn minibatch: a masked position i = ky*W + kx belongs to the minibatch iff its
-//            counter-based key is below the problem's threshold (MbDesc, written by k_draw_thr) -- the minibatch
-//            selector is never materialised: 8 KiB of mask bits per problem instead of 64 KiB written + 64 KiB read.
-enum { SEL_U8 = 0, SEL_BITS = 1, SEL_HASH = 2 };
+//   SEL_BITS a bit-packed transposed selector: word [kx][ky >> 5], bit ky & 31 -- the sampling mask itself (grad_full),
+//            or mask o device-drawn minibatch as k_draw_thr emits it (8 KiB per problem instead of a 64 KiB byte
+//            selector written by one kernel and read by the next)
+enum { SEL_U8 = 0, SEL_BITS = 1 };
 
 template <typename T, int RA, int LA, int SEL>
 __global__ __launch_bounds__(256) void k_cols(cx<T>* __restrict__ S1T, const uint8_t* __restrict__ selT,
-                                              const uint32_t* __restrict__ bitsT, const MbDesc* __restrict__ mbd,
+                                              const uint32_t* __restrict__ bitsT,
                                               const cx<T>* __restrict__ yh, const cx<T>* __restrict__ YT,
                                               const cx<T>* __restrict__ twtab, int W) {
     using S = FftSmem<T, RA, LA>;
@@ -111,14 +110,10 @@ __global__ __launch_bounds__(256) void k_cols(cx<T>* __restrict__ S1T, const uin
         const int kx = cc == 0 ? (slot == 0 ? 0 : W / 2) : (slot == 0 ? cc : W - cc);     // packed column 0 = kx 0 and W/2
         sb[slot][gg][wd] = bitsT[((size_t)prob * W + kx) * WPR + wd];
     }
-    MbDesc md = {0, 0, 0};
-    if (SEL == SEL_HASH) md = mbd[prob];
     // selector value at (kx, ky); slot says in which staged row kx sits
     auto sel_at = [&](int slot, int kx, int ky, const uint8_t* row) -> T {
         if (SEL == SEL_U8) return (T)row[ky];
-        uint32_t bit = (sb[slot][g][ky >> 5] >> (ky & 31)) & 1u;
-        if (SEL == SEL_HASH) bit &= mb_member(md, (uint32_t)(ky * W + kx)) ? 1u : 0u;
-        return (T)bit;
+        return (T)((sb[slot][g][ky >> 5] >> (ky & 31)) & 1u);
     };
 
     cx<T> v[LG], tw[LG];
@@ -390,10 +385,10 @@ extern "C" int pnp_csmri_pack_mask(pnp_csmri_plan* p, const uint8_t* selT, uint3
 }
 
 extern "C" int pnp_csmri_draw_thresholds(pnp_csmri_plan* p, const uint32_t* bitsT, int mb, uint64_t seed, uint32_t step0,
-                                         int nsteps, const uint32_t* step_dev, void* mbd, void* stream) {
+                                         int nsteps, const uint32_t* step_dev, void* mbd, uint32_t* selbits, void* stream) {
     PNP_CHECK_ARG(p && bitsT && mbd, "null argument");
     PNP_CHECK_ARG(mb >= 1 && mb <= p->H * p->W && nsteps >= 1 && nsteps <= 65535, "need 1 <= mb <= H*W, 1 <= nsteps <= 65535");
-    k_draw_thr<true><<<dim3(p->batch, nsteps), 256, 0, (hipStream_t)stream>>>(bitsT, p->H, p->W, mb, seed, step0, step_dev, (MbDesc*)mbd);
+    k_draw_thr<true><<<dim3(p->batch, nsteps), 256, 0, (hipStream_t)stream>>>(bitsT, p->H, p->W, mb, seed, step0, step_dev, (MbDesc*)mbd, selbits);
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }
@@ -409,7 +404,7 @@ extern "C" int pnp_csmri_sel_from_thresholds(pnp_csmri_plan* p, const uint32_t* 
 
 extern "C" int pnp_csmri_draw_minibatch(pnp_csmri_plan* p, const uint32_t* bitsT, int mb, uint64_t seed, uint32_t step,
                                         const uint32_t* step_dev, uint8_t* selT, void* stream) {
-    int rc = pnp_csmri_draw_thresholds(p, bitsT, mb, seed, step, 1, step_dev, p ? p->mbd : nullptr, stream);
+    int rc = pnp_csmri_draw_thresholds(p, bitsT, mb, seed, step, 1, step_dev, p ? p->mbd : nullptr, nullptr, stream);
     if (rc != PNP_OK) return rc;
     return pnp_csmri_sel_from_thresholds(p, bitsT, p->mbd, selT, stream);
 }
@@ -436,7 +431,7 @@ extern "C" int pnp_csmri_pack_y(pnp_csmri_plan* p, const void* YT, const uint8_t
 
 namespace {
 template <typename T, int RA, int LA>
-int run_grad(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const uint32_t* bitsT, const void* mbd,
+int run_grad(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const uint32_t* bitsT,
              const void* yh, const void* YT, double alpha, const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2,
              void* out, hipStream_t s) {
     constexpr int G = FftSmem<T, RA, LA>::G;
@@ -448,11 +443,9 @@ int run_grad(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* sel
     PNP_CHECK_LAUNCH();
     const dim3 cg((W / 2) / G, p->batch);
     if (selT != nullptr)
-        k_cols<T, RA, LA, SEL_U8><<<cg, 256, 0, s>>>(work, selT, nullptr, nullptr, (const cx<T>*)yh, (const cx<T>*)YT, tw, W);
-    else if (mbd == nullptr)
-        k_cols<T, RA, LA, SEL_BITS><<<cg, 256, 0, s>>>(work, nullptr, bitsT, nullptr, (const cx<T>*)yh, (const cx<T>*)YT, tw, W);
+        k_cols<T, RA, LA, SEL_U8><<<cg, 256, 0, s>>>(work, selT, nullptr, (const cx<T>*)yh, (const cx<T>*)YT, tw, W);
     else
-        k_cols<T, RA, LA, SEL_HASH><<<cg, 256, 0, s>>>(work, nullptr, bitsT, (const MbDesc*)mbd, (const cx<T>*)yh, (const cx<T>*)YT, tw, W);
+        k_cols<T, RA, LA, SEL_BITS><<<cg, 256, 0, s>>>(work, nullptr, bitsT, (const cx<T>*)yh, (const cx<T>*)YT, tw, W);
     PNP_CHECK_LAUNCH();
     k_rows_inv<T, RA, LA><<<dim3(H / (2 * G), p->batch), 256, 0, s>>>(work, tw, H, scale, (const T*)alpha_vec, (T)beta,
                                                                  (const T*)c1, (T)gamma, (const T*)c2, (T*)out);
@@ -462,14 +455,13 @@ int run_grad(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* sel
 }  // namespace
 
 extern "C" int pnp_csmri_grad_sel(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const uint32_t* bitsT,
-                                  const void* mbd, const void* yh, const void* YT, double alpha, const void* alpha_vec,
+                                  const void* yh, const void* YT, double alpha, const void* alpha_vec,
                                   double beta, const void* c1, double gamma, const void* c2, void* out, void* stream) {
     PNP_CHECK_ARG(p && a && out, "null argument");
     PNP_CHECK_ARG(!(yh != nullptr && YT != nullptr), "pass the packed data term (yh) or the raw data (YT), not both");
     PNP_CHECK_ARG((selT != nullptr) != (bitsT != nullptr), "pass either an explicit selector (selT) or mask bits (bitsT)");
-    PNP_CHECK_ARG(!(mbd != nullptr && bitsT == nullptr), "minibatch descriptors need the mask bits");
     hipStream_t s = (hipStream_t)stream;
-#define PNP_CS_ARGS p, a, b, selT, bitsT, mbd, yh, YT, alpha, alpha_vec, beta, c1, gamma, c2, out, s
+#define PNP_CS_ARGS p, a, b, selT, bitsT, yh, YT, alpha, alpha_vec, beta, c1, gamma, c2, out, s
     if (p->dtype == PNP_F32) {
         if (p->NL == 16) return run_grad<float, 16, 16>(PNP_CS_ARGS);
         if (p->NL == 12) return run_grad<float, 8, 16>(PNP_CS_ARGS);
@@ -485,5 +477,24 @@ extern "C" int pnp_csmri_grad(pnp_csmri_plan* p, const void* a, const void* b, c
                               double alpha, double beta, const void* c1, double gamma, const void* c2, void* out,
                               void* stream) {
     PNP_CHECK_ARG(selT != nullptr, "null selector");
-    return pnp_csmri_grad_sel(p, a, b, selT, nullptr, nullptr, yh, nullptr, alpha, nullptr, beta, c1, gamma, c2, out, stream);
+    return pnp_csmri_grad_sel(p, a, b, selT, nullptr, yh, nullptr, alpha, nullptr, beta, c1, gamma, c2, out, stream);
+}
+
+// ---- whole inner iteration in one kernel (csmri_fused.hip)
+namespace pnp {
+int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* b, const uint32_t* bitsT, double alpha,
+                       const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out, int denoise,
+                       double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
+                       void* stream);
+}
+
+extern "C" int pnp_csmri_svrg_step(pnp_csmri_plan* p, const void* a, const void* b, const uint32_t* bitsT, double alpha,
+                                   const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
+                                   int denoise, double sigma_modifier, double fallback_sigma, const void* xrec,
+                                   double* sse_out, void* sigma_out, void* stream) {
+    PNP_CHECK_ARG(p && a && bitsT && out, "null argument");
+    PNP_CHECK_ARG(p->dtype == PNP_F32 && p->H == 256 && p->W == 256, "the one-kernel iteration exists for f32 plans of 256 x 256");
+    PNP_CHECK_ARG(!(sse_out && !xrec), "sse_out needs xrec");
+    return csmri_fused_launch(p->batch, p->twtab, a, b, bitsT, alpha, alpha_vec, beta, c1, gamma, c2, out, denoise, sigma_modifier,
+                              fallback_sigma, xrec, sse_out, sigma_out, stream);
 }

@@ -1,7 +1,7 @@
 // draw.h -- device-side minibatch draws (problems/problem.py:110-117, problems/CSMRI.py:66-74:
 // `np.random.choice(candidates, size, replace=False)`) as counter-based keys + a threshold.
 //
-// Every candidate position i gets the 32-bit key  mix64(state + i) >> 32,  state = mix64(mix64(mix64(seed) + step) +
+// Every candidate position i gets the 32-bit key  mb_key(state, i),  state = mix64(mix64(mix64(seed) + step) +
 // problem); the `mb` smallest (key, i) pairs are the minibatch (uniform without replacement; the pairs are distinct,
 // so a draw is deterministic).  Only the THRESHOLD pair (T, P) of each (problem, step) is computed (k_draw_thr);
 // consumers re-derive membership (mb_member) where they need it, so a minibatch never exists as an array unless a
@@ -20,7 +20,16 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {      // splitmi
     return x ^ (x >> 31);
 }
 struct MbDesc { uint64_t state; uint32_t T, P; };
-__device__ __forceinline__ uint32_t mb_key(uint64_t state, uint32_t i) { return (uint32_t)(mix64(state + i) >> 32); }
+// Per-position key: a 32-bit mixer (two 32-bit multiplies; 64-bit multiplies are several quarter-rate instructions each
+// on gfx950 and this runs once per k-space position) of the position XOR the stream's low word, XOR the stream's high
+// word.  For a fixed stream it is a BIJECTION of the position, so keys never tie inside one draw.
+__host__ __device__ __forceinline__ uint32_t mb_key(uint64_t state, uint32_t i) {
+    uint32_t x = (uint32_t)state ^ i;
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x ^ (uint32_t)(state >> 32);
+}
 __device__ __forceinline__ bool mb_member(const MbDesc& d, uint32_t i) {
     const uint32_t key = mb_key(d.state, i);
     return key < d.T || (key == d.T && i <= d.P);
@@ -37,7 +46,7 @@ constexpr int DRAW_BINS = 4096, DRAW_LIST = 1024;
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_draw_thr(const uint32_t* __restrict__ bitsT, int H, int W, int mb, uint64_t seed,
                                                   uint32_t step0, const uint32_t* __restrict__ step_dev,
-                                                  MbDesc* __restrict__ mbd) {
+                                                  MbDesc* __restrict__ mbd, uint32_t* __restrict__ selbits) {
     __shared__ int hist[DRAW_BINS];
     __shared__ unsigned long long cand[DRAW_LIST];
     __shared__ int wtot[4];
@@ -60,6 +69,10 @@ __global__ __launch_bounds__(256) void k_draw_thr(const uint32_t* __restrict__ b
         return (uint32_t)(32 * wd + bt);
     };
     if (tid == 0) s_thr = ~0ull;                                 // default: every candidate (mb >= their number)
+    // selbits (optional): the minibatch itself as a bit array in the layout of the candidates ([W][H/32] words of the
+    // transposed mask, or ceil(M/32) words), one row per (step, problem) -- 8 KiB per 256 x 256 problem-step
+    uint32_t* sb = selbits != nullptr ? selbits + ((size_t)blockIdx.y * gridDim.x + prob) * nwords : nullptr;
+    bool emitted = false;
 
     uint32_t prefix = 0;                                         // the digits fixed so far (high bits of the key)
     int k = mb, fixed_bits = 0;                                  // 1-based rank still to locate inside the prefix bucket
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(256) void k_draw_thr(const uint32_t* __restrict__ b
         int base = 0;
         for (int q = 0; q < wv; ++q) base += wtot[q];
         const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        if (level == 0 && total <= mb) break;                    // uniform: every candidate is in the minibatch
+        if (level == 0 && total <= mb) break;                    // uniform: every candidate is in the minibatch (emitted below)
         const int excl = base + incl - tot;
         if (excl < k && k <= excl + tot) {                       // exactly one thread
             int before = excl, j = 0;
@@ -109,21 +122,27 @@ __global__ __launch_bounds__(256) void k_draw_thr(const uint32_t* __restrict__ b
         const int count = s_count;
         __syncthreads();
         if (count <= DRAW_LIST || level == 2) {
-            // collect the bucket's (key, i) pairs and rank them
+            // collect the bucket's (key, i) pairs and rank them; in the same sweep, emit the bits of every key BELOW
+            // the bucket (certain members) -- the bucket's own members are OR-ed in once the threshold is known
             if (tid == 0) s_n = 0;
             __syncthreads();
+            const bool emit_here = sb != nullptr && count <= DRAW_LIST;
             for (int wd = tid; wd < nwords; wd += 256) {
-                uint32_t m = word_bits(wd);
+                uint32_t m = word_bits(wd), below = 0;
                 while (m) {
                     const int bt = __builtin_ctz(m);
                     m &= m - 1;
                     const uint32_t i = pos_of(wd, bt);
                     const uint32_t key = mb_key(state, i);
-                    if ((key >> (32 - fixed_bits)) == prefix) {
+                    const uint32_t top = key >> (32 - fixed_bits);
+                    if (top == prefix) {
                         const int pos = atomicAdd(&s_n, 1);
                         if (pos < DRAW_LIST) cand[pos] = ((unsigned long long)key << 32) | i;
+                    } else if (top < prefix) {
+                        below |= 1u << bt;
                     }
                 }
+                if (emit_here) sb[wd] = below;
             }
             __syncthreads();
             if (count <= DRAW_LIST) {
@@ -132,7 +151,13 @@ __global__ __launch_bounds__(256) void k_draw_thr(const uint32_t* __restrict__ b
                     int rank = 0;
                     for (int q = 0; q < count; ++q) rank += cand[q] < mine ? 1 : 0;
                     if (rank == k - 1) s_thr = mine;
+                    if (emit_here && rank <= k - 1) {               // a member inside the threshold bucket
+                        const uint32_t i = (uint32_t)mine;
+                        if (MASKED) { const int ky = i / W, kx = i - ky * W; atomicOr(&sb[kx * wpr + (ky >> 5)], 1u << (ky & 31)); }
+                        else atomicOr(&sb[i >> 5], 1u << (i & 31));
+                    }
                 }
+                emitted = emit_here;
             } else if (tid == 0) {
                 // more than DRAW_LIST candidates share one 32-bit key (never happens with a sane hash; kept exact):
                 // walk the positions in increasing order and stop at the k-th tie
@@ -147,9 +172,18 @@ __global__ __launch_bounds__(256) void k_draw_thr(const uint32_t* __restrict__ b
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        MbDesc d = {state, (uint32_t)(s_thr >> 32), (uint32_t)s_thr};
-        mbd[(size_t)blockIdx.y * gridDim.x + prob] = d;
+    const MbDesc d = {state, (uint32_t)(s_thr >> 32), (uint32_t)s_thr};
+    if (tid == 0) mbd[(size_t)blockIdx.y * gridDim.x + prob] = d;
+    if (sb != nullptr && !emitted) {                             // everything selected, or the (never taken) slow paths
+        for (int wd = tid; wd < nwords; wd += 256) {
+            uint32_t m = word_bits(wd), sel = 0;
+            while (m) {
+                const int bt = __builtin_ctz(m);
+                m &= m - 1;
+                if (mb_member(d, pos_of(wd, bt))) sel |= 1u << bt;
+            }
+            sb[wd] = sel;
+        }
     }
 }
 

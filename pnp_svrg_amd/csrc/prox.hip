@@ -14,123 +14,17 @@
 // written once.
 #include "common.h"
 #include "reduce.h"
-#include "keys.h"
+#include "prox_tv.h"
 
 namespace pnp {
 
-// Reductions over the 4 lanes {l, l^16, l^32, l^48} that share a column, on gfx950's v_permlane16_swap /
-// v_permlane32_swap (VALU): swapping a register with a copy of itself leaves the even-row (lower-half) value in one
-// result and the odd-row (upper-half) value in the other, for both lanes of a pair.  A ds_bpermute shuffle costs ~32
-// LDS-pipe cycles per wave instruction, and the median's radix select does two of these reductions per bit.
-// Same pairing as (v + v^16) + (v^32 + v^48), so sums are bit-identical to the shuffle form.
-template <typename T> __device__ __forceinline__ void pair16(T v, T& a, T& b) {
-    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte values");
-    if constexpr (sizeof(T) == 4) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-        a = __builtin_bit_cast(T, (unsigned)r[0]); b = __builtin_bit_cast(T, (unsigned)r[1]);
-    } else {
-        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
-        a = __builtin_bit_cast(T, ((unsigned long long)hi[0] << 32) | lo[0]);
-        b = __builtin_bit_cast(T, ((unsigned long long)hi[1] << 32) | lo[1]);
-    }
-}
-template <typename T> __device__ __forceinline__ void pair32(T v, T& a, T& b) {
-    if constexpr (sizeof(T) == 4) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-        a = __builtin_bit_cast(T, (unsigned)r[0]); b = __builtin_bit_cast(T, (unsigned)r[1]);
-    } else {
-        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
-        a = __builtin_bit_cast(T, ((unsigned long long)hi[0] << 32) | lo[0]);
-        b = __builtin_bit_cast(T, ((unsigned long long)hi[1] << 32) | lo[1]);
-    }
-}
-template <typename T> __device__ __forceinline__ T col_sum(T v) {
-    T a, b;
-    pair16(v, a, b); v = a + b;
-    pair32(v, a, b); v = a + b;
-    return v;
-}
-template <typename K> __device__ __forceinline__ K col_min(K v) {
-    K a, b;
-    pair16(v, a, b); v = b < a ? b : a;
-    pair32(v, a, b); v = b < a ? b : a;
-    return v;
-}
-
-// MAD sigma of one column from this lane's chunk x[0..RPC) (all 4 lanes of the column get it).
-template <typename T, int RPC>
-__device__ __forceinline__ T column_sigma(const T (&x)[RPC], int q) {
-    using K = typename KeyOf<T>::type;
-    constexpr int NC = RPC / 2 + 1;
-    K key[NC];
-    // halo: the two samples above this chunk (symmetric extension at the top edge)
-    T up1 = __shfl_up(x[RPC - 1], 16, 64), up2 = __shfl_up(x[RPC - 2], 16, 64);
-    const T m1 = q == 0 ? x[0] : up1;      // x[-1]
-    const T m2 = q == 0 ? x[1] : up2;      // x[-2]
-    bool has_nan = false;
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        // no FMA contraction: exact zeros must stay exact zeros (they are masked out of the median)
-#pragma clang fp contract(off)
-        T d;
-        if (i == 0)              d = ((Db2<T>::h0 * x[1] + Db2<T>::h1 * x[0]) + Db2<T>::h2 * m1) + Db2<T>::h3 * m2;
-        else if (i < RPC / 2)    d = ((Db2<T>::h0 * x[2 * i + 1] + Db2<T>::h1 * x[2 * i]) + Db2<T>::h2 * x[2 * i - 1]) + Db2<T>::h3 * x[2 * i - 2];
-        else                     d = ((Db2<T>::h0 * x[RPC - 2] + Db2<T>::h1 * x[RPC - 1]) + Db2<T>::h2 * x[RPC - 1]) + Db2<T>::h3 * x[RPC - 2];
-        if (i == RPC / 2 && q != 3) d = (T)0;          // only the bottom chunk owns the extra coefficient
-        d = d < 0 ? -d : d;
-        has_nan |= (d != d);
-        const bool nz = d != (T)0;
-        n += nz ? 1 : 0;
-        key[i] = nz ? to_key(d) : ~(K)0;               // zeros are masked out of the median
-    }
-    n = col_sum(n);
-    has_nan = col_sum((int)has_nan) != 0;
-    // k-th smallest by bitwise radix select over the (monotone) bit patterns of |d|
-    const int k = (n - 1) >> 1;
-    K pfx = 0;
-#pragma unroll 1
-    for (int bit = KeyOf<T>::BITS - 1; bit >= 0; --bit) {
-        const K cand = pfx | ((K)1 << bit);
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) c += key[i] < cand ? 1 : 0;
-        c = col_sum(c);
-        if (c <= k) pfx = cand;
-    }
-    T med = from_key(pfx);
-    if ((n & 1) == 0) {                                // even count: mean of the two middle values
-        int cle = 0;
-        K nxt = ~(K)0;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            cle += key[i] <= pfx ? 1 : 0;
-            if (key[i] > pfx && key[i] < nxt) nxt = key[i];
-        }
-        cle = col_sum(cle);
-        nxt = col_min(nxt);
-        const T hi = cle > k + 1 ? med : from_key(nxt);
-        med = (med + hi) * (T)0.5;
-    }
-    if (n == 0 || has_nan) med = (T)NAN;               // np.median([]) / NaN input
-    return med / (T)0.6744897501960817;
-}
-
-template <int H> struct HaarLevels { static constexpr int value = (H >= 256 ? 5 : H >= 128 ? 4 : H >= 64 ? 3 : H >= 32 ? 2 : 1); };
-
-// MODE bit 0: denoise (else estimate only)
+// DENOISE: estimate + prox, else estimate only.  zin / zout may alias (in-place prox): no __restrict__ on them.
 template <typename T, int H, bool DENOISE>
-__global__ __launch_bounds__(1024) void k_prox_tv(const T* __restrict__ zin, T* __restrict__ zout, int W,
+__global__ __launch_bounds__(1024) void k_prox_tv(const T* zin, T* zout, int W,
                                                   const T* __restrict__ sigma_in, T sigma_modifier, T fallback_sigma,
                                                   const T* __restrict__ xrec, double* __restrict__ sse_out,
                                                   T* __restrict__ sigma_out) {
     constexpr int RPC = H / 4;
-    constexpr int L = HaarLevels<H>::value;
-    constexpr T HA = (T)0.7071067811865476;
     __shared__ double red[16];
     __shared__ T sig_sh;
     const int prob = blockIdx.x;
@@ -142,90 +36,8 @@ __global__ __launch_bounds__(1024) void k_prox_tv(const T* __restrict__ zin, T* 
     T x[RPC];
 #pragma unroll
     for (int i = 0; i < RPC; ++i) x[i] = zin[base + (size_t)i * W];
-
-    // ---------------- sigma_est = mean over columns of the per-column MAD estimate
-    T sigma_est;
-    if (sigma_in != nullptr) {
-        sigma_est = sigma_in[prob];
-    } else {
-        T sc = column_sigma<T, RPC>(x, q);
-        double part = q == 0 ? (double)sc : 0.0;
-        part = wave_sum(part);
-        if (lane == 0) red[wv] = part;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s = 0;
-            for (int i = 0; i < nwaves; ++i) s += red[i];
-            sig_sh = (T)(s / (double)W);
-        }
-        __syncthreads();
-        sigma_est = sig_sh;
-    }
-    if (sigma_out != nullptr && threadIdx.x == 0) sigma_out[prob] = sigma_est;
-    if (!DENOISE) return;
-
-    // ---------------- per-column Haar BayesShrink (TV.py:22-26)
-    const T sigma = sigma_est > (T)0 ? sigma_est * sigma_modifier : fallback_sigma;
-    const T var = sigma * sigma;
-    T thr[L];
-#pragma unroll
-    for (int lev = 0; lev < L; ++lev) {
-        const int s = 1 << lev;
-        T ss = 0;
-#pragma unroll
-        for (int j = 0; j < RPC / (2 * s); ++j) {
-            const T ev = x[2 * s * j], od = x[2 * s * j + s];
-            const T d = -HA * od + HA * ev;
-            x[2 * s * j] = HA * od + HA * ev;
-            x[2 * s * j + s] = d;
-            ss += d * d;
-        }
-        ss = col_sum(ss);
-        const T dvar = ss / (T)(H >> (lev + 1));
-        T den = dvar - var;
-        den = den > (T)2.220446049250313e-16 ? den : (T)2.220446049250313e-16;
-        thr[lev] = var / sqrt(den);
-    }
-#pragma unroll
-    for (int lev = L - 1; lev >= 0; --lev) {
-        const int s = 1 << lev;
-#pragma unroll
-        for (int j = 0; j < RPC / (2 * s); ++j) {
-            const T a = x[2 * s * j];
-            T d = x[2 * s * j + s];
-            const T mag = d < 0 ? -d : d;
-            T shr = (T)1 - thr[lev] / mag;
-            shr = shr < (T)0 ? (T)0 : shr;             // keeps NaN (0/0) like numpy clip
-            d = d * shr;
-            x[2 * s * j] = HA * a + HA * d;
-            x[2 * s * j + s] = HA * a - HA * d;
-        }
-    }
-
-    // ---------------- store + squared error against the ground truth
-    double err = 0.0;
-    if (xrec != nullptr) {
-        T e = 0;
-#pragma unroll
-        for (int i = 0; i < RPC; ++i) {
-            const T df = xrec[base + (size_t)i * W] - x[i];
-            e += df * df;
-        }
-        err = (double)e;
-    }
-#pragma unroll
-    for (int i = 0; i < RPC; ++i) zout[base + (size_t)i * W] = x[i];
-    if (sse_out != nullptr) {
-        err = wave_sum(err);
-        __syncthreads();
-        if (lane == 0) red[wv] = err;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s = 0;
-            for (int i = 0; i < nwaves; ++i) s += red[i];
-            sse_out[prob] = s;
-        }
-    }
+    prox_tv_regs<T, H, DENOISE>(x, prob, W, base, wv, lane, q, nwaves, sigma_in, sigma_modifier, fallback_sigma, xrec,
+                                DENOISE ? zout : nullptr, sse_out, sigma_out, red, &sig_sh);
 }
 
 // ------------------------------------------------------------------------------- reductions

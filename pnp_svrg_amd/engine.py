@@ -27,9 +27,11 @@ class Minibatches:
     """n slots of per-problem minibatch selections: threshold descriptors of device draws (int64 [n, B, 2]) or
     host-provided selections (slot -> whatever the batch problem's kernels take)."""
 
-    def __init__(self, n, B, device):
+    def __init__(self, n, B, device, bits_shape=None):
         self.n = n
         self.mbd = torch.zeros((n, B, 2), dtype=torch.int64, device=device)
+        # CSMRI: the device-drawn selections themselves, bit-packed (what the column pass reads)
+        self.selbits = torch.zeros((n, B) + tuple(bits_shape), dtype=torch.int32, device=device) if bits_shape else None
         self.host = [None] * n
 
 
@@ -122,9 +124,13 @@ class CsmriBatch(_BatchBase):
         return torch.from_numpy(out).to(self.device)
 
     # ---- minibatch slots
+    def minibatches(self, n):
+        return Minibatches(n, self.B, self.device, bits_shape=(self.W, self.H // 32))
+
     def draw(self, mbs, mb, seed, step0, nsteps=1, step_dev=None):
         self._check_mb(mb)
-        self.plan.draw_thresholds(self.bits, mb, seed, step0, nsteps, out=mbs.mbd[:nsteps], step_dev=step_dev)
+        self.plan.draw_thresholds(self.bits, mb, seed, step0, nsteps, out=mbs.mbd[:nsteps], step_dev=step_dev,
+                                  selbits=mbs.selbits[:nsteps])
         for j in range(nsteps):
             mbs.host[j] = None
 
@@ -135,7 +141,7 @@ class CsmriBatch(_BatchBase):
     def _sel(self, mbs, j):
         if mbs.host[j] is not None:
             return dict(selT=mbs.host[j])
-        return dict(bits=self.bits, mbd=mbs.mbd[j])
+        return dict(bits=mbs.selbits[j])
 
     # ---- gradients
     def grad_full(self, z, out, alpha=1.0, beta=0.0, c1=None):
@@ -475,6 +481,7 @@ class _StochEngine(LoopEngine):
     def _draw_slot(self, slot, step_id):
         one = Minibatches.__new__(Minibatches)
         one.n, one.mbd, one.host = 1, self.mbs.mbd[slot:slot + 1], [None]
+        one.selbits = self.mbs.selbits[slot:slot + 1] if self.mbs.selbits is not None else None
         self.b.draw(one, self.mb, self.seed, step_id, 1)
         self.mbs.host[slot] = None
 

@@ -57,14 +57,16 @@ class CsmriPlan:
         N.call('pnp_csmri_pack_mask', self._h, _p(selT), _p(out), _stream())
         return out
 
-    def draw_thresholds(self, bits, mb, seed, step0, nsteps=1, out=None, step_dev=None):
-        """Device-side minibatch draws for steps step0 .. step0+nsteps-1 of every problem: only the threshold
-        descriptors (int64 [nsteps, B, 2] = 16 bytes per (step, problem)); `grad(bits=, mbd=out[j])` consumes them."""
+    def draw_thresholds(self, bits, mb, seed, step0, nsteps=1, out=None, step_dev=None, selbits=None):
+        """Device-side minibatch draws for steps step0 .. step0+nsteps-1 of every problem: threshold descriptors
+        (int64 [nsteps, B, 2] = 16 bytes per (step, problem)) and, when `selbits` (int32 [nsteps, B, W, H/32]) is given,
+        mask o minibatch as bit-packed selectors -- `grad(bits=selbits[j])` consumes a step's row."""
         assert bits.dtype == torch.int32 and tuple(bits.shape) == (self.B, self.W, self.H // 32)
         out = out if out is not None else torch.empty((nsteps, self.B, 2), dtype=torch.int64, device=bits.device)
         assert out.dtype == torch.int64 and tuple(out.shape) == (nsteps, self.B, 2)
+        assert selbits is None or (selbits.dtype == torch.int32 and tuple(selbits.shape) == (nsteps, self.B, self.W, self.H // 32))
         N.call('pnp_csmri_draw_thresholds', self._h, _p(bits), int(mb), int(seed) & (2 ** 64 - 1), int(step0) & 0xFFFFFFFF,
-               int(nsteps), _p(step_dev), _p(out), _stream())
+               int(nsteps), _p(step_dev), _p(out), _p(selbits), _stream())
         return out
 
     def sel_from_thresholds(self, bits, mbd, out=None):
@@ -97,19 +99,18 @@ class CsmriPlan:
         return out
 
     def grad(self, a, selT=None, b=None, yh=None, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None, *,
-             bits=None, mbd=None, alpha_vec=None, YT=None):
+             bits=None, alpha_vec=None, YT=None):
         """out = alpha * alpha_vec[b] * Re ifft2(sel o fft2(a - b) - sel o Y) + beta*c1 + gamma*c2.
-        Selector: `selT` (explicit uint8 [B, W, H]) or `bits` (bit-packed mask; with `mbd` = one step's draw
-        descriptors the selector is mask o minibatch, re-derived inside the kernel).  Data term: `yh` (packed for this
+        Selector: `selT` (explicit uint8 [B, W, H]) or `bits` (bit-packed int32 [B, W, H/32]: the mask, or one step's
+        row of draw_thresholds' selbits).  Data term: `yh` (packed for this
         selector) or `YT` (complex [B, W, H], masked by the selector inside the kernel)."""
         for t in (a, b, c1, c2, out):
             assert t is None or (t.dtype == self.dtype and t.numel() == self.B * self.H * self.W)
         assert (selT is None) != (bits is None), 'pass selT or bits'
         assert alpha_vec is None or (alpha_vec.dtype == self.dtype and alpha_vec.numel() == self.B)
-        assert mbd is None or (mbd.dtype == torch.int64 and tuple(mbd.shape) == (self.B, 2))
         out = out if out is not None else torch.empty_like(a)
         assert YT is None or (YT.dtype == _CDT[self.dtype] and tuple(YT.shape) == (self.B, self.W, self.H))
-        N.call('pnp_csmri_grad_sel', self._h, _p(a), _p(b), _p(selT), _p(bits), _p(mbd), _p(yh), _p(YT), float(alpha), _p(alpha_vec),
+        N.call('pnp_csmri_grad_sel', self._h, _p(a), _p(b), _p(selT), _p(bits), _p(yh), _p(YT), float(alpha), _p(alpha_vec),
                float(beta), _p(c1), float(gamma), _p(c2), _p(out), _stream())
         return out
 

@@ -179,10 +179,18 @@ def _mix64(x):
 
 
 def _mb_keys_np(seed, step, prob, pos):
-    """NumPy restatement of the draw's counter-based key (csrc/draw.h: fields absorbed one at a time)."""
+    """NumPy restatement of the draw's counter-based key (include/pnp_hip.h, csrc/draw.h): the stream state absorbs
+    seed, step and problem one at a time (splitmix64); a position's key is a 32-bit mixer of position ^ lo32(state),
+    xor hi32(state)."""
     with np.errstate(over='ignore'):
         st = _mix64(_mix64(_mix64(np.uint64(seed)) + np.uint64(step)) + np.uint64(prob))
-        return (_mix64(st + pos.astype(np.uint64)) >> np.uint64(32)).astype(np.uint32)
+        x = (np.uint32(int(st) & 0xFFFFFFFF) ^ pos.astype(np.uint32)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        x = (x * np.uint32(0x7feb352d)).astype(np.uint32)
+        x ^= x >> np.uint32(15)
+        x = (x * np.uint32(0x846ca68b)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return (x ^ np.uint32(int(st) >> 32)).astype(np.uint32)
 
 
 def test_device_minibatch_draw():

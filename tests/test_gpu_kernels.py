@@ -160,8 +160,8 @@ def test_minmax_axpby(ops):
 
 @pytest.mark.parametrize('n,dt', [(64, torch.float64), (128, torch.float64), (256, torch.float64), (256, torch.float32)])
 def test_selector_forms_agree(ops, n, dt):
-    """The three selector forms of the column pass give the same gradient: explicit uint8 selector, bit-packed mask,
-    and mask o device-drawn minibatch re-derived from its threshold descriptor (== the materialised selector).  The
+    """The selector forms of the column pass give the same gradient: explicit uint8 selector, bit-packed mask, and
+    mask o device-drawn minibatch as the draw kernel emits it (== the selector materialised from the threshold).  The
     data term formed inside the column pass from YT == the pre-packed one (pnp_csmri_pack_y).  Per-problem alpha_vec
     == per-problem scaling afterwards."""
     rng = np.random.default_rng(n)
@@ -190,17 +190,19 @@ def test_selector_forms_agree(ops, n, dt):
     assert (g_av - 0.25 * av[:, None, None] * g_u8).abs().max().item() <= tol * max(1.0, g_u8.abs().max().item())
     # hashed minibatch == its materialised selector, with and without the data term
     mb = 150
-    mbd = plan.draw_thresholds(bits, mb, seed=11, step0=5, nsteps=3)
+    selbits = torch.empty((3, B, n, n // 32), dtype=torch.int32, device='cuda')
+    mbd = plan.draw_thresholds(bits, mb, seed=11, step0=5, nsteps=3, selbits=selbits)
     for j in range(3):
         selT = plan.sel_from_thresholds(bits, mbd[j])
         s = selT.cpu().numpy()
         assert (s.reshape(B, -1).sum(1) == mb).all() and (s <= maskT.cpu().numpy()).all()
+        assert torch.equal(plan.pack_mask(selT), selbits[j])       # the emitted bits ARE the thresholded selection
         w = dev(rng.standard_normal((B, n, n)), dt)
         a1 = plan.grad(z, selT, b=w, alpha=0.3, beta=1.0, c1=z)
-        a2 = plan.grad(z, bits=bits, mbd=mbd[j], b=w, alpha=0.3, beta=1.0, c1=z)
+        a2 = plan.grad(z, bits=selbits[j], b=w, alpha=0.3, beta=1.0, c1=z)
         assert torch.equal(a1, a2)
         b1 = plan.grad(z, selT, YT=YT)
-        b2 = plan.grad(z, bits=bits, mbd=mbd[j], YT=YT)
+        b2 = plan.grad(z, bits=selbits[j], YT=YT)
         assert torch.equal(b1, b2)
         b3 = plan.grad(z, selT, yh=plan.pack_y(YT, selT))
         assert (b1 - b3).abs().max().item() <= tol * max(1.0, b3.abs().max().item())

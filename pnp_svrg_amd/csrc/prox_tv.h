@@ -5,6 +5,7 @@
 #pragma once
 #include "common.h"
 #include "keys.h"
+#pragma clang fp contract(off)
 
 namespace pnp {
 
@@ -112,19 +113,70 @@ __device__ __forceinline__ T column_sigma(const T (&x)[RPC], int q) {
 
 template <int H> struct HaarLevels { static constexpr int value = (H >= 256 ? 5 : H >= 128 ? 4 : H >= 64 ? 3 : H >= 32 ? 2 : 1); };
 
-// The column pipeline on a register-resident image: this lane holds rows [q*RPC, (q+1)*RPC) of column `col` in x[]
-// (lane = col16 + 16*q inside wave wv, which owns columns [16 wv, 16 wv + 16)); base = element offset of x[0].
-// Whole-workgroup collective (block barriers): every thread of the one-image workgroup must call it.
-// Shared by k_prox_tv (image loaded from HBM) and the whole-iteration kernel of csmri_fused.hip (image left in
-// registers by the gradient step).
-template <typename T, int H, bool DENOISE>
-__device__ __forceinline__ void prox_tv_regs(T (&x)[H / 4], int prob, int W, size_t base, int wv, int lane, int q, int nwaves,
-                                             const T* __restrict__ sigma_in, T sigma_modifier, T fallback_sigma,
-                                             const T* __restrict__ xrec, T* __restrict__ zout, double* __restrict__ sse_out,
-                                             T* __restrict__ sigma_out, double* red, T* sig_sh) {
+// per-column multi-level Haar BayesShrink in place (denoisers/TV.py:22-26 -> skimage denoise_wavelet on one column):
+// this lane holds RPC = H/4 consecutive rows of its column in x[]; var = sigma^2
+template <typename T, int H>
+__device__ __forceinline__ void haar_bayes_shrink(T (&x)[H / 4], T var) {
     constexpr int RPC = H / 4;
     constexpr int L = HaarLevels<H>::value;
     constexpr T HA = (T)0.7071067811865476;
+    T thr[L];
+#pragma unroll
+    for (int lev = 0; lev < L; ++lev) {
+        const int s = 1 << lev;
+        T ss = 0;
+#pragma unroll
+        for (int j = 0; j < RPC / (2 * s); ++j) {
+            const T ev = x[2 * s * j], od = x[2 * s * j + s];
+            const T d = -HA * od + HA * ev;
+            x[2 * s * j] = HA * od + HA * ev;
+            x[2 * s * j + s] = d;
+            ss += d * d;
+        }
+        ss = col_sum(ss);
+        const T dvar = ss / (T)(H >> (lev + 1));
+        T den = dvar - var;
+        den = den > (T)2.220446049250313e-16 ? den : (T)2.220446049250313e-16;
+        thr[lev] = var / sqrt(den);
+    }
+#pragma unroll
+    for (int lev = L - 1; lev >= 0; --lev) {
+        const int s = 1 << lev;
+#pragma unroll
+        for (int j = 0; j < RPC / (2 * s); ++j) {
+            const T a = x[2 * s * j];
+            T d = x[2 * s * j + s];
+            const T mag = d < 0 ? -d : d;
+            T shr = (T)1 - thr[lev] / mag;
+            shr = shr < (T)0 ? (T)0 : shr;             // keeps NaN (0/0) like numpy clip
+            d = d * shr;
+            x[2 * s * j] = HA * a + HA * d;
+            x[2 * s * j + s] = HA * a - HA * d;
+        }
+    }
+}
+
+// sum over this lane's rows of (xrec - x)^2; xr points at the element of row 0 of the chunk, rows are `stride` apart
+template <typename T, int RPC>
+__device__ __forceinline__ T column_sq_err(const T (&x)[RPC], const T* __restrict__ xr, int stride) {
+    T e = 0;
+#pragma unroll
+    for (int i = 0; i < RPC; ++i) {
+        const T df = xr[(size_t)i * stride] - x[i];
+        e += df * df;
+    }
+    return e;
+}
+
+// The column pipeline on a register-resident image: this lane holds rows [q*RPC, (q+1)*RPC) of column `col` in x[]
+// (lane = col16 + 16*q inside wave wv, which owns columns [16 wv, 16 wv + 16)); base = element offset of x[0].
+// Whole-workgroup collective (block barriers): every thread of the one-image workgroup must call it.
+template <typename T, int H, bool DENOISE>
+__device__ __forceinline__ void prox_tv_regs(T (&x)[H / 4], int prob, int W, size_t base, int wv, int lane, int q, int nwaves,
+                                             const T* __restrict__ sigma_in, T sigma_modifier, T fallback_sigma,
+                                             const T* __restrict__ xrec, T* zout, double* __restrict__ sse_out,
+                                             T* __restrict__ sigma_out, double* red, T* sig_sh) {
+    constexpr int RPC = H / 4;
     // ---------------- sigma_est = mean over columns of the per-column MAD estimate
     T sigma_est;
     if (sigma_in != nullptr) {
@@ -145,57 +197,14 @@ __device__ __forceinline__ void prox_tv_regs(T (&x)[H / 4], int prob, int W, siz
     }
     if (sigma_out != nullptr && threadIdx.x == 0) sigma_out[prob] = sigma_est;
     if (DENOISE) {
-        // ---------------- per-column Haar BayesShrink (TV.py:22-26)
         const T sigma = sigma_est > (T)0 ? sigma_est * sigma_modifier : fallback_sigma;
-        const T var = sigma * sigma;
-        T thr[L];
-#pragma unroll
-        for (int lev = 0; lev < L; ++lev) {
-            const int s = 1 << lev;
-            T ss = 0;
-#pragma unroll
-            for (int j = 0; j < RPC / (2 * s); ++j) {
-                const T ev = x[2 * s * j], od = x[2 * s * j + s];
-                const T d = -HA * od + HA * ev;
-                x[2 * s * j] = HA * od + HA * ev;
-                x[2 * s * j + s] = d;
-                ss += d * d;
-            }
-            ss = col_sum(ss);
-            const T dvar = ss / (T)(H >> (lev + 1));
-            T den = dvar - var;
-            den = den > (T)2.220446049250313e-16 ? den : (T)2.220446049250313e-16;
-            thr[lev] = var / sqrt(den);
-        }
-#pragma unroll
-        for (int lev = L - 1; lev >= 0; --lev) {
-            const int s = 1 << lev;
-#pragma unroll
-            for (int j = 0; j < RPC / (2 * s); ++j) {
-                const T a = x[2 * s * j];
-                T d = x[2 * s * j + s];
-                const T mag = d < 0 ? -d : d;
-                T shr = (T)1 - thr[lev] / mag;
-                shr = shr < (T)0 ? (T)0 : shr;             // keeps NaN (0/0) like numpy clip
-                d = d * shr;
-                x[2 * s * j] = HA * a + HA * d;
-                x[2 * s * j + s] = HA * a - HA * d;
-            }
-        }
+        haar_bayes_shrink<T, H>(x, sigma * sigma);
     }
     if (zout == nullptr) return;
 
     // ---------------- store + squared error against the ground truth
     double err = 0.0;
-    if (xrec != nullptr) {
-        T e = 0;
-#pragma unroll
-        for (int i = 0; i < RPC; ++i) {
-            const T df = xrec[base + (size_t)i * W] - x[i];
-            e += df * df;
-        }
-        err = (double)e;
-    }
+    if (xrec != nullptr) err = (double)column_sq_err<T, RPC>(x, xrec + base, W);
 #pragma unroll
     for (int i = 0; i < RPC; ++i) zout[base + (size_t)i * W] = x[i];
     if (sse_out != nullptr) {

@@ -361,6 +361,16 @@ class TVProx:
                     xrec=xrec, out=z, sse=sse_out, sigma_out=self.sig)
         return z
 
+    # one-kernel iteration (pnp_csmri_svrg_step): the prox runs inside the gradient kernel
+    fused_denoise = True
+
+    def fused_args(self):
+        self.t += 1
+        return dict(sigma_modifier=self.sigma_modifier, fallback_sigma=self.denoise_strength * self.decay ** self.t, sigma_out=self.sig)
+
+    def after_fused(self, z, xrec, sse_out):
+        return z
+
 
 class DnCNNProx:
     """denoisers/RealSN_DnCNN.py semantics for the engines.  The loop's estimate_sigma is still
@@ -380,6 +390,16 @@ class DnCNNProx:
         b = self.batch
         N.call('pnp_sigma_est', ctypes.c_void_p(z.data_ptr()), b.H, b.W, b.B, 0 if b.dtype == torch.float32 else 1,
                ctypes.c_void_p(self.sig.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self.plan.denoise(z, self.sigma, xrec=xrec, out=z, sse=sse_out)
+        return z
+
+    # one-kernel iteration: the gradient kernel makes the (ignored, F12) noise estimate; the network follows
+    fused_denoise = False
+
+    def fused_args(self):
+        return dict(sigma_out=self.sig)
+
+    def after_fused(self, z, xrec, sse_out):
         self.plan.denoise(z, self.sigma, xrec=xrec, out=z, sse=sse_out)
         return z
 
@@ -503,9 +523,17 @@ class SvrgEngine(_StochEngine):
     s % T2 == 0, as in the reference's loop nest).  Device draws of a whole outer iteration are ONE launch at the
     refresh (T2 descriptor slots)."""
 
-    def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096, seed=0):
+    def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096, seed=0, fused=None):
         super().__init__(batch, prox, eta, mini_batch_size, lr_decay, n_log, seed, n_slots=T2)
         self.T2, self.variant = T2, variant
+        # the one-kernel inner iteration (csrc/csmri_fused.hip): CSMRI, f32, 256 x 256, true SVRG direction, a prox that
+        # can follow it (TV inside the kernel, DnCNN after it)
+        ok = (batch.kind == 'csmri' and batch.dtype == torch.float32 and batch.H == 256 and batch.W == 256
+              and variant == 'svrg' and hasattr(prox, 'fused_args'))
+        if fused and not ok:
+            raise ValueError('the one-kernel iteration needs a float32 256 x 256 CsmriBatch, variant="svrg" and a TV or DnCNN prox')
+        self.fused = ok if fused is None else bool(fused)
+        self._hostbits = None
         dev = batch.xrec.device
         self.w = torch.empty_like(self.z)
         self.mu = torch.empty_like(self.z)
@@ -536,12 +564,29 @@ class SvrgEngine(_StochEngine):
                 b.set_host(self.mbs, j, idx_s)
             elif self.mbs.host[j] is not None:                  # a host-fed outer iteration continued with device draws
                 self._draw_slot(j, s)
+            if self.fused:
+                self._fused_inner(j, lr, self.sse_log[self.n_prox % self.n_log])
+                self.n_prox += 1
+                self.s += 1
+                return
             b.grad_stoch_diff(self.z, self.w, self.mbs, j, out=self.z, alpha=-lr / self.mb, beta=1.0, c1=self.z,
                               gamma=-lr, c2=self.mu)
         else:
             ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
         self.z = self._prox(self.z)
         self.s += 1                                             # eager steps keep the index on the host (no counter launch)
+
+    def _fused_inner(self, j, lr, sse_out):
+        """step + estimate_sigma + prox + error of inner iteration j in one kernel (TV), or in one kernel + the network."""
+        b, px = self.b, self.prox
+        if self.mbs.host[j] is not None:                        # host-drawn selector: pack it to bits (a 5 us launch)
+            self._hostbits = b.plan.pack_mask(self.mbs.host[j], out=self._hostbits)
+            bits = self._hostbits
+        else:
+            bits = self.mbs.selbits[j]
+        b.plan.svrg_step(self.z, self.w, bits, alpha=-lr / self.mb, beta=1.0, c1=self.z, gamma=-lr, c2=self.mu, out=self.z,
+                         denoise=px.fused_denoise, xrec=b.xrec, sse=sse_out if px.fused_denoise else None, **px.fused_args())
+        px.after_fused(self.z, b.xrec, sse_out)
 
     # ---- hipGraph form: one OUTER iteration (full-gradient refresh + T2 inner iterations) = one graph launch
     def _outer_body(self):
@@ -552,13 +597,16 @@ class SvrgEngine(_StochEngine):
         if self.variant == 'svrg':
             b.draw(self.mbs, self.mb, self.seed, 0, self.T2, step_dev=self.step_dev)
         for j in range(self.T2):
-            if self.variant == 'svrg':
-                b.grad_stoch_diff(self.z, self.w, self.mbs, j, out=self.z, alpha=-lr / self.mb, beta=1.0, c1=self.z,
-                                  gamma=-lr, c2=self.mu)
+            if self.variant == 'svrg' and self.fused:
+                self._fused_inner(j, lr, self.sse_tmp)
             else:
-                ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
-            out = self.prox(self.z, b.xrec, self.sse_tmp)
-            assert out is self.z, 'graph capture needs an in-place prox'
+                if self.variant == 'svrg':
+                    b.grad_stoch_diff(self.z, self.w, self.mbs, j, out=self.z, alpha=-lr / self.mb, beta=1.0, c1=self.z,
+                                      gamma=-lr, c2=self.mu)
+                else:
+                    ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
+                out = self.prox(self.z, b.xrec, self.sse_tmp)
+                assert out is self.z, 'graph capture needs an in-place prox'
             ops.log_append(self.sse_tmp, self.sse_log, self.step_dev)
             ops.counter_add(self.step_dev, 1)
 

@@ -115,6 +115,20 @@ class CsmriPlan:
         return out
 
 
+    def svrg_step(self, a, b, bits, alpha=1.0, beta=0.0, c1=None, gamma=0.0, c2=None, out=None, *, alpha_vec=None, denoise=True,
+                  sigma_modifier=1.0, fallback_sigma=0.0, xrec=None, sse=None, sigma_out=None):
+        """pnp_csmri_svrg_step: gradient step + noise estimate (+ TV prox) + PSNR error of one inner iteration in ONE
+        kernel (f32, 256 x 256).  out = prox_TV(alpha * Re ifft2(bits o fft2(a - b)) + beta*c1 + gamma*c2)."""
+        assert self.dtype == torch.float32 and self.H == 256 and self.W == 256
+        assert bits.dtype == torch.int32 and tuple(bits.shape) == (self.B, self.W, self.H // 32)
+        out = out if out is not None else torch.empty_like(a)
+        sigma_out = sigma_out if sigma_out is not None else torch.empty(self.B, dtype=a.dtype, device=a.device)
+        N.call('pnp_csmri_svrg_step', self._h, _p(a), _p(b), _p(bits), float(alpha), _p(alpha_vec), float(beta), _p(c1),
+               float(gamma), _p(c2), _p(out), 1 if denoise else 0, float(sigma_modifier), float(fallback_sigma), _p(xrec),
+               _p(sse), _p(sigma_out), _stream())
+        return out, sse, sigma_out
+
+
 class DncnnPlan:
     """pnp_dncnn_plan_*: DnCNN-17 prox for B images of H x W (fp32 network on the f32 matrix cores).
 

@@ -376,3 +376,73 @@ def test_graph_replay_equals_eager(prox_kind):
         e1.step()
     torch.cuda.synchronize(); te = time.perf_counter() - t0
     print(f'[{prox_kind}] B={B} {n}x{n}: eager {te / (20 * T2) * 1e6:.1f} us/step, graph {tg / (20 * T2) * 1e6:.1f} us/step')
+
+
+def test_one_kernel_iteration_equals_four_kernels():
+    """pnp_csmri_svrg_step (csrc/csmri_fused.hip: SVRG step + noise estimate + TV prox + error, image register-resident)
+    against pnp_csmri_grad_sel followed by pnp_prox_tv: same stepped image / noise estimate / prox to fp32 rounding
+    (the FFTs are the same building blocks, compiled with and without FMA contraction), in place and out of place,
+    with and without the prox (denoise = 0 is what the DnCNN prox follows)."""
+    from pnp_svrg_amd import ops
+    from pnp_svrg_amd.engine import CsmriBatch
+    B, mb = 5, 1000
+    batch = CsmriBatch.synthetic(B, 256, 256, 0.2, 20.0, seed=31)
+    p = batch.plan
+    rng = np.random.default_rng(0)
+    z = batch.xinit.clone()
+    w = (batch.xinit + torch.from_numpy(0.05 * rng.standard_normal((B, 256, 256))).float().cuda()).contiguous()
+    mu = torch.from_numpy(1e-4 * rng.standard_normal((B, 256, 256))).float().cuda()
+    selbits = torch.empty((1, B, 256, 8), dtype=torch.int32, device='cuda')
+    p.draw_thresholds(batch.bits, mb, seed=3, step0=7, nsteps=1, selbits=selbits)
+    lr = 2e3
+    kw = dict(alpha=-lr / mb, beta=1.0, c1=z, gamma=-lr, c2=mu)
+    stepped = p.grad(z, bits=selbits[0], b=w, **kw)
+    want, want_sse, want_sig = ops.prox_tv(stepped, xrec=batch.xrec, sigma_modifier=1.3)
+    got, sse, sig = p.svrg_step(z, w, selbits[0], xrec=batch.xrec, sigma_modifier=1.3,
+                                sse=torch.empty(B, dtype=torch.float64, device='cuda'), **kw)
+    assert not torch.equal(want, stepped)
+    assert (sig - want_sig).abs().max().item() <= 1e-6 * want_sig.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5
+    np.testing.assert_allclose(sse.cpu().numpy(), want_sse.cpu().numpy(), rtol=1e-4)
+    # stop after the noise estimate: the stepped image itself
+    raw, _, sig0 = p.svrg_step(z, w, selbits[0], denoise=False, **kw)
+    assert (raw - stepped).abs().max().item() <= 2e-6
+    assert (sig0 - want_sig).abs().max().item() <= 1e-6 * want_sig.abs().max().item()
+    # in place (out aliases a and c1, as the engine calls it); per-problem scale; no second operand
+    z2 = z.clone()
+    p.svrg_step(z2, w, selbits[0], alpha=-lr / mb, beta=1.0, c1=z2, gamma=-lr, c2=mu, out=z2, xrec=batch.xrec, sigma_modifier=1.3)
+    assert torch.equal(z2, got)
+    av = torch.tensor([0.5, 2.0, 1.0, 0.25, 3.0], device='cuda')
+    g1, _, _ = p.svrg_step(z, None, batch.bits, alpha=1e-4, alpha_vec=av, denoise=False)
+    g2 = p.grad(z, bits=batch.bits, alpha=1e-4, alpha_vec=av)
+    assert (g1 - g2).abs().max().item() <= 2e-6 * max(1.0, g2.abs().max().item())
+
+
+@pytest.mark.parametrize('prox_kind', ['tv', 'dncnn'])
+def test_fused_engine_equals_unfused(prox_kind):
+    """SvrgEngine with the one-kernel iteration (default for f32 256 x 256 CSMRI) walks the trajectory of the
+    four-kernel engine: device draws or host index lists, eager and hipGraph forms."""
+    from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, TVProx, DnCNNProx
+    from pnp_svrg_amd.denoisers import random_dncnn_weights
+    B, mb, T2, steps = 3, 1000, 4, 8
+    mk = (lambda: TVProx(sigma_modifier=1.1)) if prox_kind == 'tv' else (lambda: DnCNNProx(random_dncnn_weights(17, seed=1), 15))
+    eta = 2e3 if prox_kind == 'tv' else 1.0
+    batch = CsmriBatch.synthetic(B, 256, 256, 0.2, 20.0, seed=13)
+    for host in (False, True):
+        ef = SvrgEngine(batch, mk(), eta, T2, mb, seed=4)
+        eu = SvrgEngine(batch, mk(), eta, T2, mb, seed=4, fused=False)
+        assert ef.fused and not eu.fused
+        idx = batch.draw_minibatches(steps, mb, seed=2) if host else None
+        for s in range(steps):
+            ef.step(None if idx is None else idx[s])
+            eu.step(None if idx is None else idx[s])
+        assert (ef.z - eu.z).abs().max().item() <= 5e-5 * max(1.0, eu.z.abs().max().item())
+        assert np.abs(ef.psnr_trace() - eu.psnr_trace()).max() <= 0.01 + 1e-9
+    g = SvrgEngine(batch, mk(), eta, T2, mb, seed=4)
+    g.capture()
+    g.run_outer(steps // T2)
+    e = SvrgEngine(batch, mk(), eta, T2, mb, seed=4)
+    for s in range(steps):
+        e.step()
+    assert torch.equal(g.z, e.z) and np.array_equal(g.psnr_trace(), e.psnr_trace())
+    assert type(g.prox).__name__ != 'TVProx' or g.prox.t == e.prox.t == steps

@@ -27,6 +27,7 @@
 //     matrix pipe is the only busy resource by a wide margin.
 #include "common.h"
 #include "f16x3.h"
+#include "wino4.h"
 #include "tilewalk.h"
 #include "reduce.h"
 #include <vector>
@@ -652,6 +653,7 @@ using namespace pnp;
 struct pnp_dncnn_plan {
     int n_mid, H, W, batch, num_cu;
     float *w_first, *w_last, *wpack, *upack, *bias;   // device (upack: Winograd F(2,3)-transformed weights)
+    float* upack4;                               // Winograd F(4,3)-transformed weights (dncnn_wino4.hip)
     void* wpack16;                               // split-fp16 weight fragments (mode 3, dncnn_f16x3.hip)
     float* b_first;                              // [64] device, zeros unless pnp_dncnn_set_affine
     float b_last, slope;                         // last-layer bias, LeakyReLU slope (0 = ReLU)
@@ -706,14 +708,23 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
                     upk[(((size_t)l * 4 + wv) * WINO_U + s) * 64 + lane] = (float)u;
                 }
     {
+        // conv kernel of the middle layers: 4 = Winograd F(4,3) (default where the image size allows it), 1 = F(2,3),
+        // 0 = direct, 3 = opt-in split-fp16
         const char* ev = getenv("PNP_DNCNN_WINOGRAD");
-        p->use_wino = ev ? atoi(ev) : 1;
+        p->use_wino = ev ? atoi(ev) : 4;
+        if (p->use_wino == 4 && !wino4_supports(H, W)) p->use_wino = 1;
     }
     const size_t act_bytes = (size_t)batch * C * H * W * sizeof(float);
     hipError_t e = hipMalloc(&p->wpack, pack.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->wpack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->upack, upk.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->upack, upk.data(), upk.size() * sizeof(float), hipMemcpyHostToDevice);
+    {
+        std::vector<float> u4(wino4_weight_floats(n_mid));
+        wino4_pack_weights(w_mid, n_mid, u4.data());
+        if (e == hipSuccess) e = hipMalloc(&p->upack4, u4.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p->upack4, u4.data(), u4.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&p->bias, (size_t)n_mid * C * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->bias, b_mid, (size_t)n_mid * C * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->w_first, C * 9 * sizeof(float));
@@ -737,7 +748,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e != hipSuccess) {
         set_error(std::string("pnp_dncnn_plan_create: ") + hipGetErrorString(e));
         for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
-                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16})
+                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16, (void*)p->upack4})
             if (q) (void)hipFree(q);
         delete p;
         return PNP_ERR_HIP;
@@ -749,7 +760,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
 extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
     if (!p) return PNP_OK;
     for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
-                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16})
+                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16, (void*)p->upack4})
         (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -782,6 +793,10 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
         if (p->use_wino == 3) {
             const int rc = f16x3_layer(src, dst, (const unsigned char*)p->wpack16 + f16x3_weight_bytes(1) * (size_t)l,
                                        p->bias + (size_t)l * C, p->zeros, H, W, B, p->num_cu, l == p->n_mid - 1, p->slope, s);
+            if (rc != PNP_OK) return rc;
+        } else if (p->use_wino == 4) {
+            const int rc = wino4_layer(src, dst, p->upack4 + (size_t)l * wino4_weight_floats(1), p->bias + (size_t)l * C, p->zeros,
+                                       H, W, B, p->num_cu, p->slope, s);
             if (rc != PNP_OK) return rc;
         } else if (p->slope != 0.f) {                             // LeakyReLU builds exist for the two production kernels
             if (p->use_wino)
@@ -824,7 +839,9 @@ extern "C" int pnp_dncnn_set_affine(pnp_dncnn_plan* p, const float* b_first, flo
 
 extern "C" int pnp_dncnn_set_winograd(pnp_dncnn_plan* p, int enable) {
     PNP_CHECK_ARG(p != nullptr, "null plan");
-    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 3, "mode must be 0 (direct), 1 (Winograd) or 3 (split-fp16)");
+    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 3 || enable == 4,
+                  "mode must be 0 (direct), 1 (Winograd F(2,3)), 3 (split-fp16) or 4 (Winograd F(4,3))");
+    PNP_CHECK_ARG(!(enable == 4 && !wino4_supports(p->H, p->W)), "Winograd F(4,3) needs H % 4 == 0 and W % 64 == 0");
     p->use_wino = enable;
     return PNP_OK;
 }

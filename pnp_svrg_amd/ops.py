@@ -139,8 +139,9 @@ class DncnnPlan:
     `transpose_taps` (every 3x3 kernel transposed) cover the MMO `simple_CNN` (denoisers/MMODenoise.py:73-101)."""
 
     def __init__(self, weights, H, W, batch, winograd=None):
-        """winograd: True = F(2,3) conv kernel (default; fp32, 2/3 of the matrix-core work),
-        False = direct implicit GEMM (bit-for-bit an fmaf chain), None = env PNP_DNCNN_WINOGRAD or True."""
+        """winograd: 4 = Winograd F(4,3) conv kernel (default where W % 64 == 0; fp32, half of the matrix-core work),
+        True / 1 = F(2,3) (two thirds), False / 0 = direct implicit GEMM (bit-for-bit an fmaf chain), 3 = opt-in
+        split-fp16, None = env PNP_DNCNN_WINOGRAD or the default."""
         import numpy as np
         require_gpu()
         n = int(weights['n_layers'])
@@ -175,7 +176,7 @@ class DncnnPlan:
             b_last = float(np.asarray(weights.get(f'conv{n - 1}.bias', 0.0)).reshape(-1)[0])
             N.call('pnp_dncnn_set_affine', self._h, b_first.ctypes.data_as(ctypes.c_void_p), b_last, slope)
         if winograd is not None:
-            N.call('pnp_dncnn_set_winograd', self._h, int(winograd))   # 0 direct, 1 Winograd, 2 Winograd two-WG/CU
+            N.call('pnp_dncnn_set_winograd', self._h, int(winograd))
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None

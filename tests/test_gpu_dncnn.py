@@ -81,16 +81,21 @@ def test_winograd_vs_direct(W15, io):
     x = dev(io['net256_in'][None])
     rw = ops.DncnnPlan(W15, 256, 256, 1, winograd=True).forward(x).cpu().numpy()[0]
     rd = ops.DncnnPlan(W15, 256, 256, 1, winograd=False).forward(x).cpu().numpy()[0]
-    assert not np.array_equal(rw, rd)                          # really two different kernels
-    assert np.abs(rw - rd).max() <= 1e-5
+    r4 = ops.DncnnPlan(W15, 256, 256, 1, winograd=4).forward(x).cpu().numpy()[0]       # F(4,3): the default
+    assert np.array_equal(r4, ops.DncnnPlan(W15, 256, 256, 1).forward(x).cpu().numpy()[0])
+    assert not np.array_equal(rw, rd) and not np.array_equal(r4, rw)      # really three different kernels
+    assert np.abs(rw - rd).max() <= 1e-5 and np.abs(r4 - rd).max() <= 1e-5
     assert np.abs(rw - io['net256_out']).max() <= 2e-5 and np.abs(rd - io['net256_out']).max() <= 2e-5
+    assert np.abs(r4 - io['net256_out']).max() <= 2e-5
+    print('max |conv kernel - reference net|: F(4,3) %.2e  F(2,3) %.2e  direct %.2e' % (
+        np.abs(r4 - io['net256_out']).max(), np.abs(rw - io['net256_out']).max(), np.abs(rd - io['net256_out']).max()))
     # several tiles per persistent workgroup in the XCD-aware order (tilewalk.h), and a count that does not divide
     # (plain walk): every image of a batch must equal its single-image result, for all conv kernels
     rng = np.random.default_rng(5)
     for B in (6, 5):
         xb = rng.random((B, 256, 256)).astype(np.float32)
         xb[B - 1] = io['net256_in']
-        for mode in (1, 0):
+        for mode in (4, 1, 0):
             rb = ops.DncnnPlan(W15, 256, 256, B, winograd=mode).forward(dev(xb)).cpu().numpy()
             one = ops.DncnnPlan(W15, 256, 256, 1, winograd=mode).forward(dev(xb[1:2])).cpu().numpy()[0]
             assert np.array_equal(rb[1], one), (B, mode)
@@ -107,7 +112,7 @@ def test_simplecnn_family(name):
     w = {'n_layers': np.int64(4)}
     for i in range(4):
         w[f'conv{i}.weight'] = g[f'{name}_conv{i}.weight']
-    for wino in (1, 0):
+    for wino in (4, 1, 0):
         r = ops.DncnnPlan(w, 64, 64, 1, winograd=wino).forward(dev(g['net64_in'][None])).cpu().numpy()[0]
         assert np.abs(r - g[f'{name}_out']).max() <= 2e-5
 

@@ -12,12 +12,15 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { P_ADD, P_PK, P_DS, P_MIXS, P_MIXB, P_MIXS2 };
+enum { P_ADD, P_PK, P_DS, P_MIXS, P_MIXB, P_MIXS2, P_FMA, P_PKFMA, P_PKFMA_S, P_BLOCK_FMA, P_BLOCK_PKFMA };
 
 #define MFMA(i) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[(i) & 15]) : "a"(a), "v"(b))
 #define VADD(j) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(j) & 15]) : "v"(v[((j) + 5) & 15]))
 #define VSUB(j) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[(j) & 15]) : "v"(v[((j) + 5) & 15]))
 #define VPK(j) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[(j) & 7]) : "v"(p[((j) + 3) & 7]))
+#define VFMA(j) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(v[(j) & 15]) : "v"(v[((j) + 5) & 15]), "v"(v[((j) + 9) & 15]))
+#define VPKFMA(j) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[(j) & 7]) : "v"(p[((j) + 3) & 7]), "v"(p[((j) + 5) & 7]))
+#define VPKFMAS(j) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[(j) & 7]) : "s"(kc), "v"(p[((j) + 5) & 7]))
 #define DSR(j) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d[(j) & 15]) : "v"(laddr), "n"(((j) & 15) * 2), "n"(((j) & 15) * 2 + 1) : "memory")
 
 template <int PAT, int K, int M>
@@ -35,8 +38,17 @@ __global__ __launch_bounds__(256, 1) void k(const float* src, float* out, unsign
     const unsigned laddr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + 4u * (threadIdx.x & 63) * 2u;
     const float* gsrc = src + (threadIdx.x & 63) * 4;
     float* dma_dst = lds + 8192 + (threadIdx.x >> 6) * 256;
+    const unsigned long long kc = 0x4080000040800000ull;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
+        if (PAT == P_BLOCK_FMA) {
+#pragma unroll
+            for (int j = 0; j < 36; ++j) VFMA(j);
+        }
+        if (PAT == P_BLOCK_PKFMA) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) VPKFMA(j);
+        }
         if (PAT == P_MIXB) {
 #pragma unroll
             for (int j = 0; j < 10; ++j) DSR(j);
@@ -51,6 +63,15 @@ __global__ __launch_bounds__(256, 1) void k(const float* src, float* out, unsign
             if (PAT == P_ADD) {
 #pragma unroll
                 for (int j = 0; j < K; ++j) { if (j & 1) VSUB(i + j); else VADD(i + j); }
+            } else if (PAT == P_FMA) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) VFMA(i + j);
+            } else if (PAT == P_PKFMA) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) VPKFMA(i + j);
+            } else if (PAT == P_PKFMA_S) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) VPKFMAS(i + j);
             } else if (PAT == P_PK) {
 #pragma unroll
                 for (int j = 0; j < K; ++j) VPK(i + j);
@@ -106,6 +127,13 @@ int main() {
     run<P_ADD, 8, 1>("8 v_add/sub_f32 / gap", src, out, cyc);
     run<P_PK, 1, 1>("1 v_pk_add_f32 / gap", src, out, cyc);
     run<P_PK, 2, 1>("2 v_pk_add_f32 / gap", src, out, cyc);
+    run<P_FMA, 1, 1>("1 v_fma_f32 / gap", src, out, cyc);
+    run<P_FMA, 2, 1>("2 v_fma_f32 / gap", src, out, cyc);
+    run<P_PKFMA, 1, 1>("1 v_pk_fma_f32 / gap", src, out, cyc);
+    run<P_PKFMA, 2, 1>("2 v_pk_fma_f32 / gap", src, out, cyc);
+    run<P_PKFMA_S, 1, 1>("1 v_pk_fma_f32 (SGPR const) / gap", src, out, cyc);
+    run<P_BLOCK_FMA, 0, 1>("block of 36 v_fma_f32 / 48 MFMA", src, out, cyc);
+    run<P_BLOCK_PKFMA, 0, 1>("block of 18 v_pk_fma_f32 / 48 MFMA", src, out, cyc);
     run<P_DS, 1, 1>("1 ds_read2_b32 / gap", src, out, cyc);
     run<P_DS, 1, 2>("1 ds_read2_b32 / 2 gaps", src, out, cyc);
     run<P_DS, 2, 1>("2 ds_read2_b32 / gap", src, out, cyc);

@@ -60,7 +60,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=None,
                     help='independent reconstructions per GPU (default: 120 = one Set12 x 10 sampling-ratio sweep for dncnn, '
-                         '256 for tv, 64 for saga-nlm)')
+                         '1024 for tv (SURVEY 8d batch list), 64 for saga-nlm)')
     ap.add_argument('--workload', default='dncnn', choices=['dncnn', 'tv', 'saga-nlm'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-2 / config-4 secondary measurements')
@@ -217,7 +217,8 @@ class Workload:
             alg = TV_BYTES_PER_ITER * B
             ach = alg / dt_step / 1e9
             return {'bound': 'hbm',
-                    'kernel': 'whole inner iteration (k_rows_fwd + k_cols<hashed minibatch> + k_rows_inv + k_prox_tv; 1/T2 of k_draw_thr)',
+                    'kernel': 'whole inner iteration = pnp::k_svrg_iter<true> (SVRG step through the masked FFT, noise estimate, Haar prox, '
+                              'error sum in one kernel, image register-resident) + 1/T2 of k_draw_thr and of the full-gradient refresh',
                     'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                     'traffic': _traffic(f'tv_step_B{B}'), 'bytes_per_step': alg}
         # saga-nlm: the NLM prox dominates (VALU-bound patch search); the table update is the HBM-bound part
@@ -329,7 +330,7 @@ def main():
     from pnp_svrg_amd.denoisers import random_dncnn_weights
     ops.require_gpu()
 
-    B = a.batch if a.batch is not None else {'dncnn': 120, 'tv': 256, 'saga-nlm': 64}[a.workload]
+    B = a.batch if a.batch is not None else {'dncnn': 120, 'tv': 1024, 'saga-nlm': 64}[a.workload]
     # the reference's own DnCNN sigma=15 weights (committed fixture) when present, else random init
     wfile = os.path.join(ROOT, 'tests', 'golden', 'dncnn_noise15.npz')
     weights = dict(np.load(wfile)) if os.path.exists(wfile) else random_dncnn_weights(17, seed=0)
@@ -376,7 +377,7 @@ def main():
             secondary = {}
             del w.eng, w.prox, w.batch
             torch.cuda.empty_cache()
-            for name, bb, st in (('tv', 256, 200), ('saga-nlm', 64, 20)):
+            for name, bb, st in (('tv', 1024, 100), ('saga-nlm', 64, 20)):
                 w2 = Workload(name, bb, rank, a)
                 dt2 = measure(w2, st, 10 if name == 'tv' else 3, sync_all)
                 if name == 'saga-nlm':

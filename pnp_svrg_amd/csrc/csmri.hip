@@ -388,7 +388,7 @@ extern "C" int pnp_csmri_draw_thresholds(pnp_csmri_plan* p, const uint32_t* bits
                                          int nsteps, const uint32_t* step_dev, void* mbd, uint32_t* selbits, void* stream) {
     PNP_CHECK_ARG(p && bitsT && mbd, "null argument");
     PNP_CHECK_ARG(mb >= 1 && mb <= p->H * p->W && nsteps >= 1 && nsteps <= 65535, "need 1 <= mb <= H*W, 1 <= nsteps <= 65535");
-    k_draw_thr<true><<<dim3(p->batch, nsteps), 256, 0, (hipStream_t)stream>>>(bitsT, p->H, p->W, mb, seed, step0, step_dev, (MbDesc*)mbd, selbits);
+    k_draw_thr<true><<<dim3(p->batch, nsteps), 256, 0, (hipStream_t)stream>>>(bitsT, p->H, p->W, mb, seed, step0, step_dev, (MbDesc*)mbd, selbits, draw_fast_path());
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }

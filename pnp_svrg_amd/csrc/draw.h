@@ -10,8 +10,11 @@
 // the host.
 #pragma once
 #include "common.h"
+#include <cstdlib>
 
 namespace pnp {
+
+inline int draw_fast_path() { return getenv("PNP_DRAW_NO_FAST") == nullptr ? 1 : 0; }
 
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {      // splitmix64 finaliser
     x += 0x9E3779B97F4A7C15ull;
@@ -46,7 +49,7 @@ constexpr int DRAW_BINS = 4096, DRAW_LIST = 1024;
 template <bool MASKED>
 __global__ __launch_bounds__(256) void k_draw_thr(const uint32_t* __restrict__ bitsT, int H, int W, int mb, uint64_t seed,
                                                   uint32_t step0, const uint32_t* __restrict__ step_dev,
-                                                  MbDesc* __restrict__ mbd, uint32_t* __restrict__ selbits) {
+                                                  MbDesc* __restrict__ mbd, uint32_t* __restrict__ selbits, int fast) {
     __shared__ int hist[DRAW_BINS];
     __shared__ unsigned long long cand[DRAW_LIST];
     __shared__ int wtot[4];
@@ -73,6 +76,68 @@ __global__ __launch_bounds__(256) void k_draw_thr(const uint32_t* __restrict__ b
     // transposed mask, or ceil(M/32) words), one row per (step, problem) -- 8 KiB per 256 x 256 problem-step
     uint32_t* sb = selbits != nullptr ? selbits + ((size_t)blockIdx.y * gridDim.x + prob) * nwords : nullptr;
     bool emitted = false;
+
+    // ---- fast path: ONE sweep over the candidates.  The rank-mb key of M0 i.i.d. uniform keys sits near mb/M0 * 2^32
+    // with a standard deviation of ~sqrt(mb) key spacings; keys below a +-3.5 sigma window (in units of the top 12 bits) are
+    // certain members, keys inside it are collected and ranked exactly (the ranking is quadratic in their number, hence 3.5 sigma: one draw in ~2000 misses).  If the window misses (or overflows the list)
+    // the general radix select below takes over, so the result is the same either way (`fast` = 0, set by the environment
+    // variable PNP_DRAW_NO_FAST, forces the general select: tests compare the two).
+    if (fast) {
+        int m0 = 0;
+        for (int wd = tid; wd < nwords; wd += 256) m0 += __builtin_popcount(word_bits(wd));
+        m0 = wave_sum(m0);
+        if (lane == 0) wtot[wv] = m0;
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        m0 = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+        if (m0 > mb) {
+            const float per_bucket = (float)m0 / (float)DRAW_BINS;
+            const float bg = (float)mb / per_bucket, wdt = 3.5f * sqrtf((float)mb) / per_bucket + 1.f;
+            const int lo = (int)fmaxf(0.f, floorf(bg - wdt)), hi = (int)fminf((float)(DRAW_BINS - 1), ceilf(bg + wdt));
+            int below = 0;
+            for (int wd = tid; wd < nwords; wd += 256) {
+                uint32_t m = word_bits(wd), bl = 0;
+                while (m) {
+                    const int bt = __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint32_t i = pos_of(wd, bt);
+                    const uint32_t key = mb_key(state, i);
+                    const int top = (int)(key >> 20);
+                    if (top < lo) {
+                        bl |= 1u << bt;
+                    } else if (top <= hi) {
+                        const int pos = atomicAdd(&s_n, 1);
+                        if (pos < DRAW_LIST) cand[pos] = ((unsigned long long)key << 32) | i;
+                    }
+                }
+                below += __builtin_popcount(bl);
+                if (sb != nullptr) sb[wd] = bl;
+            }
+            below = wave_sum(below);
+            if (lane == 0) wtot[wv] = below;
+            __syncthreads();
+            const int before = wtot[0] + wtot[1] + wtot[2] + wtot[3], ncand = s_n, kk = mb - before;
+            if (ncand <= DRAW_LIST && kk >= 1 && kk <= ncand) {             // uniform across the workgroup
+                for (int a = tid; a < ncand; a += 256) {
+                    const unsigned long long mine = cand[a];
+                    int rank = 0;
+                    for (int q = 0; q < ncand; ++q) rank += cand[q] < mine ? 1 : 0;
+                    if (rank == kk - 1) {
+                        const MbDesc d = {state, (uint32_t)(mine >> 32), (uint32_t)mine};
+                        mbd[(size_t)blockIdx.y * gridDim.x + prob] = d;
+                    }
+                    if (sb != nullptr && rank <= kk - 1) {
+                        const uint32_t i = (uint32_t)mine;
+                        if (MASKED) { const int ky = i / W, kx = i - ky * W; atomicOr(&sb[kx * wpr + (ky >> 5)], 1u << (ky & 31)); }
+                        else atomicOr(&sb[i >> 5], 1u << (i & 31));
+                    }
+                }
+                return;
+            }
+            __syncthreads();                                     // fall back to the general select
+        }
+    }
 
     uint32_t prefix = 0;                                         // the digits fixed so far (high bits of the key)
     int k = mb, fixed_bits = 0;                                  // 1-based rank still to locate inside the prefix bucket

@@ -67,7 +67,7 @@ extern "C" int pnp_draw_thresholds(int M, int batch, int mb, uint64_t seed, uint
                                    const uint32_t* step_dev, void* mbd, void* stream) {
     PNP_CHECK_ARG(mbd != nullptr, "null argument");
     PNP_CHECK_ARG(M >= 1 && batch >= 1 && mb >= 1 && nsteps >= 1 && nsteps <= 65535, "need M, batch, mb >= 1 and 1 <= nsteps <= 65535");
-    k_draw_thr<false><<<dim3(batch, nsteps), 256, 0, (hipStream_t)stream>>>(nullptr, 1, M, mb, seed, step0, step_dev, (MbDesc*)mbd, nullptr);
+    k_draw_thr<false><<<dim3(batch, nsteps), 256, 0, (hipStream_t)stream>>>(nullptr, 1, M, mb, seed, step0, step_dev, (MbDesc*)mbd, nullptr, draw_fast_path());
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }

@@ -164,7 +164,7 @@ def test_bench_default_line_has_secondary_configs():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert 0 < line['roofline']['frac'] < 1 and line['config']['batch_per_gpu'] == 120
     sec = line['secondary']
-    assert sec['tv']['roofline']['bound'] == 'hbm' and 0 < sec['tv']['roofline']['frac'] < 1
+    assert sec['tv']['roofline']['bound'] == 'hbm' and 0 < sec['tv']['roofline']['frac'] < 1 and sec['tv']['config']['batch_per_gpu'] == 1024
     assert sec['saga-nlm']['roofline']['bound'] == 'valu' and sec['saga-nlm']['value'] > 0
     assert sec['saga-nlm']['roofline']['saga_table_update']['bound'] == 'hbm'
     assert sec['tv']['psnr_db']['after_timed_steps_mean'] > sec['tv']['psnr_db']['initial_mean']
@@ -250,6 +250,32 @@ def test_device_minibatch_draw_known_answer(n, frac):
             T, P = keys[order[-1]], pos[order[-1]]
             d = mbd[t, b].cpu().numpy().view(np.uint32)           # {state lo, state hi, T, P}
             assert (int(d[2]), int(d[3])) == (int(T), int(P))
+
+
+def test_draw_fast_path_equals_general_select(monkeypatch):
+    """The draw kernel's one-sweep fast path (window around the expected threshold) and its general radix select
+    (PNP_DRAW_NO_FAST=1) produce the same descriptors and bits, masked and unmasked, incl. mb close to M0."""
+    from pnp_svrg_amd import ops
+    n, B = 256, 3
+    rng = np.random.default_rng(4)
+    plan = ops.CsmriPlan(n, n, B, torch.float32)
+    mask = (rng.random((B, n, n)) < np.array([0.2, 0.05, 0.6])[:, None, None]).astype(np.uint8)
+    bits = plan.pack_mask(plan.sel_from_dense(torch.from_numpy(mask).cuda()))
+    m0min = int(mask.reshape(B, -1).sum(1).min())
+    for mb in (1, 1000, m0min - 1, m0min):
+        out = {}
+        for fast in (True, False):
+            if fast:
+                monkeypatch.delenv('PNP_DRAW_NO_FAST', raising=False)
+            else:
+                monkeypatch.setenv('PNP_DRAW_NO_FAST', '1')
+            sb = torch.zeros((2, B, n, n // 32), dtype=torch.int32, device='cuda')
+            mbd = plan.draw_thresholds(bits, mb, seed=99, step0=3, nsteps=2, selbits=sb)
+            gen = ops.draw_thresholds(5000, B, min(mb, 4999), seed=99, step0=3, nsteps=2)
+            out[fast] = (mbd.clone(), sb.clone(), gen.clone())
+        for a, b in zip(out[True], out[False]):
+            assert torch.equal(a, b), mb
+    monkeypatch.delenv('PNP_DRAW_NO_FAST', raising=False)
 
 
 def test_device_draw_seeds_are_independent():

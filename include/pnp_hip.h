@@ -240,6 +240,8 @@ int pnp_dncnn_debug_clock(pnp_dncnn_plan* plan, int reps, double* cycles, double
  * depends on a host-side step index).  pnp_log_append: log[(*step_dev % n_log)][0..n) = src[0..n).        */
 int pnp_counter_add(uint32_t* counter, uint32_t inc, void* stream);
 int pnp_log_append(const double* src, int n, double* log, int n_log, const uint32_t* step_dev, void* stream);
+/* the same with a log-owned counter that the call also advances: log[(*counter % n_log)] = src; ++*counter          */
+int pnp_log_append_inc(const double* src, int n, double* log, int n_log, uint32_t* counter, void* stream);
 
 /* ------------------------------------------------------------------ minibatches over M measurements, SAGA table
  * Problem.select_mb (problems/problem.py:110-117: `np.random.choice(M, size, replace=False)` -> 0/1 indicator) on the

@@ -15,6 +15,7 @@ TOL = 1e-5
 
 class CountingClock:
     """Deterministic stand-in for time.time(): returns 0, 1, 2, ... (one tick per call)."""
+    deterministic = True            # (the product's loops may pre-compute their schedule from such a clock)
 
     def __init__(self):
         self.n = -1.0

@@ -28,6 +28,7 @@ SIGNATURES = {
     'pnp_csmri_draw_minibatch': (_i, [_vp, _vp, _i, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, _vp]),
     'pnp_counter_add': (_i, [_vp, ctypes.c_uint32, _vp]),
     'pnp_log_append': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    'pnp_log_append_inc': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     'pnp_csmri_sel_from_dense': (_i, [_vp, _vp, _vp, _vp]),
     'pnp_csmri_pack_y': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pnp_csmri_grad': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _d, _vp, _vp, _vp]),

@@ -24,6 +24,22 @@ from . import ops
 tol = 1e-5
 
 
+class CountingClock:
+    """Deterministic stand-in for time.time(): returns 0, 1, 2, ... (one tick per call).  Passing one as `clock=` fixes
+    the iteration count of a loop (the reference loops are wall-clock bounded) and, because the schedule then does not
+    depend on the device, lets pnp_svrg replay whole outer iterations as hipGraphs (`graph=`)."""
+    deterministic = True
+
+    def __init__(self):
+        self.n = -1.0
+
+    def __call__(self):
+        self.n += 1.0
+        return self.n
+
+    time = __call__
+
+
 # ------------------------------------------------------------------------------------------
 # small adaptor layer: vectors are device tensors for native problems, NumPy arrays otherwise
 # ------------------------------------------------------------------------------------------
@@ -202,11 +218,155 @@ def pnp_saga(problem, denoiser, eta, tt, mini_batch_size, hist_size=50, verbose=
     return c.result(z, 'pnp_saga')
 
 
+class _SvrgGraph:
+    """One outer iteration of pnp_svrg on a native CSMRI problem (B = 1) as a hipGraph: full gradient, w = z, PSNR log,
+    T2 x (selector from the host-drawn index list, SVRG step, prox, PSNR log).  Minibatch index lists live in a device
+    buffer that the host refills before every replay (they come from the legacy np.random stream); squared errors go to
+    a device log that is read back once at the end.  At B = 1 an inner iteration is ~8 small kernels, so launch
+    latency is the whole cost: a replay removes it."""
+
+    def __init__(self, problem, denoiser, eta, T2, mb, variant, n_log):
+        p = self.p = problem
+        self.d, self.eta, self.T2, self.mb, self.variant = denoiser, eta, T2, mb, variant
+        dev, H, W = p.device, p.H, p.W
+        self.z = p.to_device(p.Xinit).clone().reshape(1, H, W)
+        self.w = torch.empty_like(self.z)
+        self.mu = torch.empty_like(self.z)
+        self.idx = torch.zeros((T2, 1, mb), dtype=torch.int32, device=dev)
+        self.selT = torch.empty_like(p._maskT)
+        self.sse = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.log = torch.zeros((n_log, 1), dtype=torch.float64, device=dev)
+        self.cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.graph = None
+
+    def log_psnr(self):
+        ops.sse(self.z, self.p._xrec_d, out=self.sse)
+        ops.log_append_inc(self.sse, self.log, self.cnt)
+
+    def refresh(self):
+        p = self.p
+        p.plan.grad(self.z, p._maskT, yh=p._yh_full, alpha=1.0 / p.M0, out=self.mu)
+        self.w.copy_(self.z)
+        self.log_psnr()
+
+    def inner(self, j):
+        p, lr = self.p, self.eta
+        if self.variant == 'svrg':
+            p.plan.sel_from_indices(self.idx[j], out=self.selT)
+            p.plan.grad(self.z, self.selT, b=self.w, alpha=-lr / self.mb, beta=1.0, c1=self.z, gamma=-lr, c2=self.mu, out=self.z)
+        else:
+            ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
+        self.d.prox_inplace(self.z, self.p._xrec_d, self.sse)
+        ops.log_append_inc(self.sse, self.log, self.cnt)
+
+    def outer_body(self):
+        self.refresh()
+        for j in range(self.T2):
+            self.inner(j)
+
+    def capture(self):
+        keep = (self.z.clone(), self.log.clone(), self.cnt.clone())
+        t0 = getattr(self.d, 't', 0)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.outer_body()                                   # warm-up outside capture (lazy module loads)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.t_per_outer = getattr(self.d, 't', 0) - t0          # the denoiser's call counter advances per prox (TV.py:22)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.outer_body()
+        torch.cuda.synchronize()
+        for dst, src in zip((self.z, self.log, self.cnt), keep):
+            dst.copy_(src)
+        if hasattr(self.d, 't'):
+            self.d.t = t0
+        self.graph = g
+
+    def upload(self, outers):
+        """all minibatch index lists of the run in ONE host-to-device copy: [outer][T2][mb] (rows of a short last outer
+        iteration stay zero and are never read)"""
+        buf = np.zeros((max(len(outers), 1), self.T2, self.mb), np.int32)
+        for o, lists in enumerate(outers):
+            for j, l in enumerate(lists):
+                buf[o, j] = l
+        self.all_idx = torch.from_numpy(buf).to(self.p.device)
+
+    def run_outer(self, o, n):
+        """outer iteration o with n <= T2 inner iterations (a short last one runs eagerly)"""
+        self.idx.copy_(self.all_idx[o].reshape(self.T2, 1, self.mb))     # device-to-device, stream-ordered
+        if n == self.T2:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+            if hasattr(self.d, 't'):
+                self.d.t += self.t_per_outer
+        else:
+            self.refresh()
+            for j in range(n):
+                self.inner(j)
+
+
+def _svrg_graph_schedule(c, problem, tt, T2, mini_batch_size):
+    """Dry run of pnp_svrg's loop nest against a deterministic clock: the same clock() calls in the same order, the same
+    select_mb draws from the legacy np.random stream, the same time bookkeeping -- and no device work.  Returns the
+    minibatch index lists per outer iteration."""
+    # a select_mb that is the class's own (not overridden / monkeypatched) can skip building the H x W indicator
+    fast = (hasattr(problem, '_select_mb_locs') and 'select_mb' not in problem.__dict__
+            and type(problem).select_mb.__qualname__ == 'CSMRI.select_mb')
+    elapsed = c.clock()
+    c.time_per_iter.append(c.clock() - elapsed)
+    outers = []
+    while (c.clock() - elapsed) < tt:
+        start_time = c.clock()
+        c.time_per_iter.append(c.clock() - start_time)
+        lists = []
+        for j in range(T2):
+            if (c.clock() - elapsed) >= tt:
+                break
+            g0 = c.clock()
+            if fast:
+                locs = problem._select_mb_locs(mini_batch_size)
+            else:
+                mb = problem.select_mb(mini_batch_size)
+                locs = np.flatnonzero(np.multiply(problem.mask, np.asarray(mb).reshape(problem.H, problem.W)))
+            ge = c.clock() - g0
+            c.gradient_time += ge
+            d0 = c.clock()
+            de = c.clock() - d0
+            c.denoise_time += de
+            c.time_per_iter.append(ge + de)
+            lists.append(locs)
+        outers.append(lists)
+    return outers
+
+
+def _svrg_graph_eligible(c, problem, denoiser, clock, lr_decay, verbose, converge_check, diverge_check):
+    return (c.native and getattr(problem, 'pname', '') == 'csmri' and hasattr(problem, 'plan') and
+            getattr(clock, 'deterministic', False) and lr_decay == 1 and not verbose and converge_check is not True
+            and diverge_check is not True and hasattr(denoiser, 'prox_inplace') and denoiser.prox_inplace(None, None, None, probe=True))
+
+
 def pnp_svrg(problem, denoiser, eta, tt, T2, mini_batch_size, verbose=True, lr_decay=1, converge_check=True,
-             diverge_check=False, *, clock=None, variant='reference'):
+             diverge_check=False, *, clock=None, variant='reference', graph=None):
+    """graph (extension): None = replay whole outer iterations as hipGraphs when nothing in the loop depends on the
+    device -- a deterministic `clock` (CountingClock), no convergence / divergence test, lr_decay == 1, not verbose, a
+    native CSMRI problem and an in-place native prox; False = never.  Same results either way."""
     if variant not in ('reference', 'svrg'):
         raise ValueError("variant must be 'reference' (v = mu, what the reference executes) or 'svrg'")
     c = _Ctx(problem, denoiser, clock)
+    if graph is not False and _svrg_graph_eligible(c, problem, denoiser, clock, lr_decay, verbose, converge_check, diverge_check):
+        outers = _svrg_graph_schedule(c, problem, tt, T2, mini_batch_size)
+        n_log = 1 + sum(1 + len(l) for l in outers)
+        run = _SvrgGraph(problem, denoiser, eta, T2, mini_batch_size, variant, n_log)
+        run.upload(outers)
+        run.log_psnr()                                          # the initial entry
+        for o, lists in enumerate(outers):
+            run.run_outer(o, len(lists))
+        sse = run.log[:, 0].cpu().numpy()
+        c.psnr_per_iter = [problem.psnr_from_sse(v, problem.N) for v in sse]
+        return c.result(run.z.reshape(-1), 'PnP SVRG')
     z = c.init()
     fused = variant == 'svrg' and c.native and hasattr(problem, 'grad_stoch_diff')
     i = 0

@@ -143,6 +143,22 @@ __global__ void k_log_append(const double* __restrict__ src, int n, double* __re
     if (i < n) log[(size_t)(*step_dev % (uint32_t)n_log) * n + i] = src[i];
 }
 
+// log[(*counter % n_log)][0..n) = src[0..n), then ++*counter: one block, so the increment follows every read of the counter
+__global__ __launch_bounds__(256) void k_log_append_inc(const double* __restrict__ src, int n, double* __restrict__ log, int n_log,
+                                                        uint32_t* __restrict__ counter) {
+    const uint32_t row = *counter % (uint32_t)n_log;
+    for (int i = threadIdx.x; i < n; i += 256) log[(size_t)row * n + i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) *counter += 1;
+}
+
+extern "C" int pnp_log_append_inc(const double* src, int n, double* log, int n_log, uint32_t* counter, void* stream) {
+    PNP_CHECK_ARG(src && log && counter && n >= 1 && n_log >= 1, "bad argument");
+    k_log_append_inc<<<1, 256, 0, (hipStream_t)stream>>>(src, n, log, n_log, counter);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+
 extern "C" int pnp_counter_add(uint32_t* counter, uint32_t inc, void* stream) {
     PNP_CHECK_ARG(counter != nullptr, "null counter");
     k_counter_add<<<1, 64, 0, (hipStream_t)stream>>>(counter, inc);

@@ -60,6 +60,15 @@ class TVDenoiser(Denoise):
             return out.reshape(noisy.shape)
         return out.reshape(H, W).double().cpu().numpy()
 
+    def prox_inplace(self, z, xrec, sse, probe=False):
+        """estimate_sigma + denoise + error sum on z in place, nothing allocated, no per-call host state: what a
+        hipGraph can hold.  probe=True only answers whether this instance can (the decaying fixed strength cannot)."""
+        if probe:
+            return self.denoise_strength == 0
+        self.t += 1
+        ops.prox_tv(z, sigma_modifier=self.sigma_modifier, fallback_sigma=0.0, xrec=xrec, out=z, sse=sse)
+        return True
+
 
 class BM3DDenoiser(Denoise):
     """reference denoisers/BM3D.py wraps the closed-source PyPI `bm3d` binaries: out of scope
@@ -148,6 +157,14 @@ class RealSN_DnCNNDenoiser(Denoise):
         B, H, W = z.shape
         out, sse = self._plan(B, H, W).denoise(z, self.sigma, xrec=xrec, out=out, sse=sse)
         return out, sse, None
+
+    def prox_inplace(self, z, xrec, sse, probe=False):
+        """denoise + error sum on z in place (plan-owned workspaces: nothing allocated), for hipGraph capture."""
+        if probe:
+            return True
+        B, H, W = z.shape
+        self._plan(B, H, W).denoise(z, self.sigma, xrec=xrec, out=z, sse=sse)
+        return True
 
     def denoise(self, noisy, sigma_est=0):
         z = _as_dev(noisy)

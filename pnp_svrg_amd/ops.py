@@ -439,3 +439,9 @@ def log_append(src, log, step_dev):
     """log[(step % n_log)] = src; src: float64 [n], log: float64 [n_log, n], step_dev: device counter."""
     require_gpu()
     N.call('pnp_log_append', _p(src), src.numel(), _p(log), log.shape[0], _p(step_dev), _stream())
+
+
+def log_append_inc(src, log, counter):
+    """log[(counter % n_log)] = src; counter += 1 (one launch; counter: int32 device tensor with one element)."""
+    require_gpu()
+    N.call('pnp_log_append_inc', _p(src), src.numel(), _p(log), log.shape[0], _p(counter), _stream())

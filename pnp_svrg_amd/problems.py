@@ -216,6 +216,16 @@ class CSMRI(Problem):
         batch[batch_locs] = 1
         return batch.reshape(self.H, self.W).astype(int)
 
+    def _select_mb_locs(self, size):
+        """The draw of select_mb without building the H x W indicator: the same np.random.choice call on the same
+        (cached) array of sampled locations, so the legacy stream advances identically."""
+        if size > self.M:
+            print('MB size is too big: ', size, ' > ', self.M)
+        locs = self.__dict__.get('_mask_locs')
+        if locs is None:
+            locs = self._mask_locs = np.asarray(np.flatnonzero(self.mask))
+        return np.random.choice(locs, size, replace=False)
+
     def _selector(self, mb):
         """mask o mb (CSMRI.py:84) -> transposed device selector."""
         sel = np.flatnonzero(np.multiply(self.mask, np.asarray(mb).reshape(self.H, self.W))).astype(np.int32)

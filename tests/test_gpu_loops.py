@@ -303,3 +303,52 @@ def test_config3_split_fp16_conv_vs_oracle(api, g_csmri, monkeypatch):
     assert len(ps) == len(pso) == 13 and np.abs(ps - pso).max() <= 0.01 + 1e-9, (ps, pso)
     assert np.abs(out['3']['z'] - ro['z']).max() < 5e-4
     assert np.abs(out['3']['z'] - out['1']['z']).max() < 1e-5
+
+
+def test_svrg_graph_replay_equals_eager_loop(api):
+    """pnp_svrg with a deterministic clock replays whole outer iterations as hipGraphs (graph=None): identical result
+    dict to the eager loop (graph=False) -- iterate, PSNR log, time bookkeeping, RNG stream position, denoiser call
+    counter -- for both directions, f32 and f64, incl. a short last outer iteration; and it is what removes the launch
+    latency at B = 1."""
+    import time
+    A, P, D = api
+    for dtype in (torch.float32, torch.float64):
+        for variant in ('reference', 'svrg'):
+            res = []
+            for graph in (None, False):
+                p = _csmri(P, IMG256, 256, dtype)
+                np.random.seed(1)
+                d = D.TVDenoiser()
+                # 2 + 3 outer x 3 + 5 x 27 ticks: two full outer iterations of 10 and a last one of 7
+                r = A.pnp_svrg(p, d, 2e3, 2 + 3 * 3 + 5 * 27 - 1, 10, 1000, verbose=False, converge_check=False,
+                               clock=A.CountingClock(), variant=variant, graph=graph)
+                res.append((r, d.t, np.random.random()))
+            (rg, tg, ug), (re, te, ue) = res
+            assert len(rg['psnr_per_iter']) == 1 + 3 + 27 and rg['psnr_per_iter'] == re['psnr_per_iter']
+            assert np.array_equal(rg['z'], re['z'])
+            assert rg['time_per_iter'] == re['time_per_iter'] and rg['gradient_time'] == re['gradient_time']
+            assert rg['denoise_time'] == re['denoise_time'] and tg == te == 27 and ug == ue
+    # launch latency: 256 x 256, B = 1, TV prox, true SVRG
+    times = {}
+    for graph in (None, False):
+        p = _csmri(P, IMG256, 256, torch.float32)
+        np.random.seed(1)
+        n = 200
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        A.pnp_svrg(p, D.TVDenoiser(), 2e3, 2 + 3 * (n // 10) + 5 * n - 1, 10, 1000, verbose=False, converge_check=False,
+                   clock=A.CountingClock(), variant='svrg', graph=graph)
+        torch.cuda.synchronize(); times[graph] = (time.perf_counter() - t0) / n * 1e6
+    print(f'drop-in pnp_svrg + TV, 256x256, B = 1: hipGraph {times[None]:.1f} us/inner iteration (incl. host minibatch draws), eager {times[False]:.1f}')
+    # the device side alone: replays of one captured outer iteration (T2 = 10 inner iterations)
+    from pnp_svrg_amd.algorithms import _SvrgGraph
+    p = _csmri(P, IMG256, 256, torch.float32)
+    run = _SvrgGraph(p, D.TVDenoiser(), 2e3, 10, 1000, 'svrg', 4096)
+    run.upload([[p._select_mb_locs(1000) for _ in range(10)]])
+    run.run_outer(0, 10)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50):
+        run.graph.replay()
+    torch.cuda.synchronize()
+    dev_us = (time.perf_counter() - t0) / 500 * 1e6
+    print(f'device side of the replayed loop: {dev_us:.1f} us per inner iteration (incl. 1/10 of the full-gradient refresh)')
+    assert dev_us < 400      # (at B = 1 the one-workgroup-per-image kernels are bound by a single CU, not by launches)

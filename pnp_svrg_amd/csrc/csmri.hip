@@ -323,6 +323,7 @@ struct pnp_csmri_plan {
     void* work;     // [batch][W/2][H] complex
     void* twtab;    // [N] complex
     void* mbd;      // [batch] MbDesc scratch of pnp_csmri_draw_minibatch
+    int fused_min_batch;   // batches at least this large take the one-kernel gradient (env PNP_CSMRI_FUSED_MIN_BATCH)
 };
 
 extern "C" int pnp_csmri_plan_create(pnp_csmri_plan** out, int H, int W, int batch, int dtype) {
@@ -330,7 +331,8 @@ extern "C" int pnp_csmri_plan_create(pnp_csmri_plan** out, int H, int W, int bat
     PNP_CHECK_ARG(H == W && (H == 64 || H == 128 || H == 256), "supported sizes: H == W in {64, 128, 256}");
     PNP_CHECK_ARG(batch >= 1, "batch must be >= 1");
     PNP_CHECK_ARG(dtype == PNP_F32 || dtype == PNP_F64, "dtype must be PNP_F32 or PNP_F64");
-    auto* p = new pnp_csmri_plan{H, W, batch, dtype, H == 256 ? 16 : H == 128 ? 12 : 8, nullptr, nullptr, nullptr};
+    auto* p = new pnp_csmri_plan{H, W, batch, dtype, H == 256 ? 16 : H == 128 ? 12 : 8, nullptr, nullptr, nullptr, 192};
+    if (const char* ev = getenv("PNP_CSMRI_FUSED_MIN_BATCH")) p->fused_min_batch = atoi(ev);
     const size_t esz = dtype == PNP_F32 ? 8 : 16;
     hipError_t e = hipMalloc(&p->work, (size_t)batch * (W / 2) * H * esz);
     if (e == hipSuccess) e = hipMalloc(&p->twtab, (size_t)H * esz);
@@ -429,6 +431,13 @@ extern "C" int pnp_csmri_pack_y(pnp_csmri_plan* p, const void* YT, const uint8_t
     return PNP_OK;
 }
 
+namespace pnp {
+int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* b, const uint32_t* bitsT, const void* yh,
+                       double alpha, const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
+                       int mode, double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
+                       void* stream);
+}
+
 namespace {
 template <typename T, int RA, int LA>
 int run_grad(pnp_csmri_plan* p, const void* a, const void* b, const uint8_t* selT, const uint32_t* bitsT,
@@ -460,6 +469,11 @@ extern "C" int pnp_csmri_grad_sel(pnp_csmri_plan* p, const void* a, const void* 
     PNP_CHECK_ARG(p && a && out, "null argument");
     PNP_CHECK_ARG(!(yh != nullptr && YT != nullptr), "pass the packed data term (yh) or the raw data (YT), not both");
     PNP_CHECK_ARG((selT != nullptr) != (bitsT != nullptr), "pass either an explicit selector (selT) or mask bits (bitsT)");
+    // large f32 256 x 256 batches with a bit-packed selector: the three passes in ONE kernel, the spectrum never in HBM
+    // (csmri_fused.hip; one workgroup per image, so it needs about a workgroup per CU to pay off)
+    if (p->dtype == PNP_F32 && p->H == 256 && bitsT != nullptr && YT == nullptr && p->batch >= p->fused_min_batch)
+        return csmri_fused_launch(p->batch, p->twtab, a, b, bitsT, yh, alpha, alpha_vec, beta, c1, gamma, c2, out, 2, 1.0, 0.0,
+                                  nullptr, nullptr, nullptr, stream);
     hipStream_t s = (hipStream_t)stream;
 #define PNP_CS_ARGS p, a, b, selT, bitsT, yh, YT, alpha, alpha_vec, beta, c1, gamma, c2, out, s
     if (p->dtype == PNP_F32) {
@@ -481,13 +495,6 @@ extern "C" int pnp_csmri_grad(pnp_csmri_plan* p, const void* a, const void* b, c
 }
 
 // ---- whole inner iteration in one kernel (csmri_fused.hip)
-namespace pnp {
-int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* b, const uint32_t* bitsT, double alpha,
-                       const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out, int denoise,
-                       double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
-                       void* stream);
-}
-
 extern "C" int pnp_csmri_svrg_step(pnp_csmri_plan* p, const void* a, const void* b, const uint32_t* bitsT, double alpha,
                                    const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
                                    int denoise, double sigma_modifier, double fallback_sigma, const void* xrec,
@@ -495,6 +502,6 @@ extern "C" int pnp_csmri_svrg_step(pnp_csmri_plan* p, const void* a, const void*
     PNP_CHECK_ARG(p && a && bitsT && out, "null argument");
     PNP_CHECK_ARG(p->dtype == PNP_F32 && p->H == 256 && p->W == 256, "the one-kernel iteration exists for f32 plans of 256 x 256");
     PNP_CHECK_ARG(!(sse_out && !xrec), "sse_out needs xrec");
-    return csmri_fused_launch(p->batch, p->twtab, a, b, bitsT, alpha, alpha_vec, beta, c1, gamma, c2, out, denoise, sigma_modifier,
-                              fallback_sigma, xrec, sse_out, sigma_out, stream);
+    return csmri_fused_launch(p->batch, p->twtab, a, b, bitsT, nullptr, alpha, alpha_vec, beta, c1, gamma, c2, out, denoise ? 0 : 1,
+                              sigma_modifier, fallback_sigma, xrec, sse_out, sigma_out, stream);
 }

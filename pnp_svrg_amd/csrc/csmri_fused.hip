@@ -102,7 +102,7 @@ __device__ __forceinline__ void col_load(cx<float> (&v)[16], const cx<float>* ld
 }
 
 __device__ __forceinline__ void col_transform(cx<float> (&v)[16], const cx<float>* twl, cx<float>* scr, const uint32_t* sb,
-                                              const ColPair& c, int l) {
+                                              const ColPair& c, int l, const cx<float>* __restrict__ yhc) {
     fft256<false>(v, twl, scr, l);                          // along h: element ky = l + 16 r
     auto bit = [&](int slot, int ky) -> float { return (float)((sb[slot * 8 + (ky >> 5)] >> (ky & 31)) & 1u); };
     if (c.packed) {
@@ -130,6 +130,10 @@ __device__ __forceinline__ void col_transform(cx<float> (&v)[16], const cx<float
             v[r] = {wgt * v[r].x, wgt * v[r].y};
         }
     }
+    if (yhc != nullptr) {                                   // packed data term of this half-spectrum column (pnp_csmri_pack_y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = csub(v[r], yhc[l + 16 * r]);
+    }
     fft256<true>(v, twl, scr, l);                           // back to h = l + 16 r
 }
 
@@ -154,8 +158,8 @@ __device__ __forceinline__ void col_store(const cx<float> (&v)[16], cx<float>* l
 // memory clobbers, which the compiler may ignore for loads it knows to be invariant.
 __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const float* a, const float* b,
                                                const uint32_t* __restrict__ bits, const cx<float>* twl, cx<float>* ldc,
-                                               uint32_t (*sbits)[2][16], float scale, float beta, const float* c1, float gamma,
-                                               const float* c2, int g, int l) {
+                                               uint32_t (*sbits)[2][16], const cx<float>* __restrict__ yh, float scale, float beta,
+                                               const float* c1, float gamma, const float* c2, int g, int l) {
     cx<float>* scr = ldc + g * F_SCR;
     unsigned off[FP];                                       // element offset of (row 2rp, column l); row 2rp+1 is +FN
 #pragma unroll
@@ -204,10 +208,12 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
             }
         // this group's two column pairs and their selector bits (rows ca and W - ca of the transposed bit mask)
         ColPair cp[2];
+        const cx<float>* yhc[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int idx = k * FG + g;                     // 0..63
             const int ca = half == 0 ? idx : 64 + idx;
+            yhc[k] = yh != nullptr ? yh + (size_t)ca * FN : nullptr;
             const bool packed = half == 0 && idx == 0;      // columns 0 and 128
             const int cb = packed ? 128 : FN - ca;
             cp[k] = {kx_local(ca, half), kx_local(cb, half), packed};
@@ -218,9 +224,9 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
         col_load(v0, ldc, cp[0], l);
         col_load(v1, ldc, cp[1], l);
         __syncthreads();                                    // every group has its columns: the buffer becomes FFT scratch
-        col_transform(v0, twl, scr, sbits[g][0], cp[0], l);
+        col_transform(v0, twl, scr, sbits[g][0], cp[0], l, yhc[0]);
         asm volatile("" ::: "memory");                      // one transform's working registers at a time
-        col_transform(v1, twl, scr, sbits[g][1], cp[1], l);
+        col_transform(v1, twl, scr, sbits[g][1], cp[1], l, yhc[1]);
         __syncthreads();                                    // all FFT scratch use is over: the buffer carries data again
         col_store(v0, ldc, cp[0], l);
         col_store(v1, ldc, cp[1], l);
@@ -277,14 +283,20 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
 
 namespace pnp {
 
+// MODE: 0 = the whole iteration; 1 = stop after the noise estimate and store the stepped image (another prox follows);
+//       2 = the gradient only (phases 1-3, stored in row order: grad_full with its data term, or any other use of
+//           pnp_csmri_grad_sel that fits this kernel).
 // STOP (diagnostic builds, PNP_FUSED_STOP): leave after phase STOP with a checksum store, to time the phases one by one
-template <bool DENOISE, int STOP>
+enum { FUSED_FULL = 0, FUSED_NO_DENOISE = 1, FUSED_GRAD = 2 };
+template <int MODE, int STOP>
 __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b,
-                                                  const uint32_t* __restrict__ bitsT, const cx<float>* __restrict__ twtab,
+                                                  const uint32_t* __restrict__ bitsT, const cx<float>* __restrict__ yh,
+                                                  const cx<float>* __restrict__ twtab,
                                                   float scale, const float* __restrict__ alpha_vec, float beta, const float* c1,
                                                   float gamma, const float* c2, float* out,
                                                   float sigma_modifier, float fallback_sigma, const float* __restrict__ xrec,
                                                   double* __restrict__ sse_out, float* __restrict__ sigma_out) {
+    constexpr bool DENOISE = MODE == FUSED_FULL;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     cx<float>* ldc = reinterpret_cast<cx<float>*>(lds_raw);
     float* ldf = reinterpret_cast<float*>(lds_raw);
@@ -300,8 +312,19 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     __syncthreads();
 
     cx<float> Z[FP][16];
-    fused_gradient(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twl, ldc, sbits, scale, beta,
+    fused_gradient(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twl, ldc, sbits,
+                   yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
                    c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l);
+    if (MODE == FUSED_GRAD) {
+        float* oi = out + img;
+#pragma unroll
+        for (int p = 0; p < FP; ++p) {
+            const unsigned o = (unsigned)(2 * (p * FG + g)) * FN + l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oi[o + 16 * r] = Z[p][r].x; oi[o + FN + 16 * r] = Z[p][r].y; }
+        }
+        return;
+    }
     if (STOP == 3) {
         float acc = 0.f;
 #pragma unroll
@@ -346,6 +369,20 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     const unsigned base0 = (unsigned)(q * 64) * FN + 16 * wv + cl, base1 = base0 + 128;   // inside this image
     float* oi = out + img;
     const float* xri = xrec != nullptr ? xrec + img : nullptr;
+    const bool want_err = DENOISE && xri != nullptr;
+    // The ground truth for the error sum arrives by LDS-DMA while the noise estimate computes (the LDS is idle from here
+    // on): columns [0, 128) of all 256 rows = 128 KiB as [row][128]; one wave instruction moves two rows (1 KiB).
+    auto dma_xrec = [&](int colbase) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int pc = wv + 8 * k;                          // 128 pieces, 16 per wave
+            const float* src = xri + (unsigned)(2 * pc + (lane64 >> 5)) * FN + colbase + 4 * (lane64 & 31);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ldf + pc * 256), 16, 0, 0);
+        }
+    };
+    __syncthreads();                                            // the re-layout reads of every wave are done
+    if (want_err) dma_xrec(0);
     // sigma_est = mean over the 256 columns of the per-column MAD estimate
     {
         const float s0 = column_sigma<float, 64>(x[0], q), s1 = column_sigma<float, 64>(x[1], q);
@@ -368,14 +405,24 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
         haar_bayes_shrink<float, FN>(x[1], sigma * sigma);
     }
     double err = 0.0;
-    if (xrec != nullptr) {
-        err = (double)column_sq_err<float, 64>(x[0], xri + base0, FN) + (double)column_sq_err<float, 64>(x[1], xri + base1, FN);
+    const float* xl = ldf + (64 * q) * 128 + 16 * wv + cl;      // this lane's column in the staged [row][128] block
+    if (want_err) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // columns [0, 128) of the ground truth have landed
+        err = (double)column_sq_err<float, 64>(x[0], xl, 128);
+        __syncthreads();
+        dma_xrec(128);                                          // columns [128, 256) under the first half's stores
     }
 #pragma unroll
     for (int i = 0; i < 64; ++i) oi[base0 + (unsigned)i * FN] = x[0][i];
+    if (want_err) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        err += (double)column_sq_err<float, 64>(x[1], xl, 128);
+    }
 #pragma unroll
     for (int i = 0; i < 64; ++i) oi[base1 + (unsigned)i * FN] = x[1][i];
-    if (sse_out != nullptr) {
+    if (sse_out != nullptr && want_err) {
         err = wave_sum(err);
         __syncthreads();
         if (lane64 == 0) red[wv] = err;
@@ -388,10 +435,11 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     }
 }
 
-// plan internals live in csmri.hip (pnp_csmri_svrg_step); the kernel only needs the plan's twiddle table
-int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* b, const uint32_t* bitsT, double alpha,
-                       const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out, int denoise,
-                       double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
+// plan internals live in csmri.hip (pnp_csmri_svrg_step / pnp_csmri_grad_sel); the kernel only needs the plan's twiddle table.
+// mode: FUSED_FULL / FUSED_NO_DENOISE / FUSED_GRAD
+int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* b, const uint32_t* bitsT, const void* yh,
+                       double alpha, const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
+                       int mode, double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
                        void* stream) {
     const float scale = (float)(alpha / ((double)FN * (double)FN));
     hipStream_t s = (hipStream_t)stream;
@@ -402,21 +450,24 @@ int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* 
     int dev = 0;
     PNP_CHECK_HIP(hipGetDevice(&dev));
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
         attr_done |= 1ull << (dev & 63);
     }
-#define PNP_FUSED_LAUNCH(DN, ST)                                                                                          \
-    k_svrg_iter<DN, ST><<<batch, FT, F_LDS_BYTES, s>>>((const float*)a, (const float*)b, bitsT, (const cx<float>*)twtab, scale,   \
-                                                       (const float*)alpha_vec, (float)beta, (const float*)c1, (float)gamma,    \
-                                                       (const float*)c2, (float*)out, (float)sigma_modifier,                  \
-                                                       (float)fallback_sigma, (const float*)xrec, sse_out, (float*)sigma_out)
-    if (stop == 3) PNP_FUSED_LAUNCH(true, 3);
-    else if (stop == 4) PNP_FUSED_LAUNCH(true, 4);
-    else if (denoise) PNP_FUSED_LAUNCH(true, 0);
-    else PNP_FUSED_LAUNCH(false, 0);
+#define PNP_FUSED_LAUNCH(MD, ST)                                                                                          \
+    k_svrg_iter<MD, ST><<<batch, FT, F_LDS_BYTES, s>>>((const float*)a, (const float*)b, bitsT, (const cx<float>*)yh,          \
+                                                       (const cx<float>*)twtab, scale, (const float*)alpha_vec, (float)beta,    \
+                                                       (const float*)c1, (float)gamma, (const float*)c2, (float*)out,         \
+                                                       (float)sigma_modifier, (float)fallback_sigma, (const float*)xrec,      \
+                                                       sse_out, (float*)sigma_out)
+    if (mode == FUSED_GRAD) PNP_FUSED_LAUNCH(2, 0);
+    else if (stop == 3) PNP_FUSED_LAUNCH(0, 3);
+    else if (stop == 4) PNP_FUSED_LAUNCH(0, 4);
+    else if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0, 0);
+    else PNP_FUSED_LAUNCH(1, 0);
 #undef PNP_FUSED_LAUNCH
     PNP_CHECK_LAUNCH();
     return PNP_OK;

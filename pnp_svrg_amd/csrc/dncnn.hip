@@ -534,7 +534,7 @@ constexpr int LT_R = 16, LT_C = 64, LT_CK = 4, LT_PR = LT_R + 2, LT_PC = LT_C + 
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_last(const float* __restrict__ act, const float* __restrict__ w,
-                                              const T* __restrict__ zin, const T* __restrict__ mm,
+                                              const T* zin, const T* __restrict__ mm,      // zin may alias zout (in-place prox): no __restrict__
                                               T* zout, float* __restrict__ r_out,
                                               const T* __restrict__ xrec, double* __restrict__ sse_part, int H, int W,
                                               double srange, double sshift, int skip01, float blast) {

@@ -522,6 +522,7 @@ class SvrgEngine(_StochEngine):
     executes (v = mu, :54).  `step()` = one inner iteration (the outer full-gradient refresh happens inside when
     s % T2 == 0, as in the reference's loop nest).  Device draws of a whole outer iteration are ONE launch at the
     refresh (T2 descriptor slots)."""
+    FUSED_MIN_BATCH = 192
 
     def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096, seed=0, fused=None):
         super().__init__(batch, prox, eta, mini_batch_size, lr_decay, n_log, seed, n_slots=T2)
@@ -532,7 +533,9 @@ class SvrgEngine(_StochEngine):
               and variant == 'svrg' and hasattr(prox, 'fused_args'))
         if fused and not ok:
             raise ValueError('the one-kernel iteration needs a float32 256 x 256 CsmriBatch, variant="svrg" and a TV or DnCNN prox')
-        self.fused = ok if fused is None else bool(fused)
+        # one workgroup per image: it pays off from about a workgroup per CU (measured: B = 120 is slower than the
+        # streaming kernels, B = 256 faster), so small batches keep the four streaming kernels unless asked otherwise
+        self.fused = (ok and batch.B >= self.FUSED_MIN_BATCH) if fused is None else bool(fused)
         self._hostbits = None
         dev = batch.xrec.device
         self.w = torch.empty_like(self.z)

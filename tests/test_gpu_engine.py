@@ -442,6 +442,17 @@ def test_one_kernel_iteration_equals_four_kernels():
     g1, _, _ = p.svrg_step(z, None, batch.bits, alpha=1e-4, alpha_vec=av, denoise=False)
     g2 = p.grad(z, bits=batch.bits, alpha=1e-4, alpha_vec=av)
     assert (g1 - g2).abs().max().item() <= 2e-6 * max(1.0, g2.abs().max().item())
+    # gradient-only mode with the packed data term (what grad_full of a large batch takes): force it on this small batch
+    import os
+    from pnp_svrg_amd import ops as _ops
+    os.environ['PNP_CSMRI_FUSED_MIN_BATCH'] = '1'
+    try:
+        pf = _ops.CsmriPlan(256, 256, B, torch.float32)
+    finally:
+        del os.environ['PNP_CSMRI_FUSED_MIN_BATCH']
+    gf1 = pf.grad(z, bits=batch.bits, yh=batch.yh_full, alpha=0.7, alpha_vec=batch.inv_m0, beta=0.5, c1=w)
+    gf2 = p.grad(z, bits=batch.bits, yh=batch.yh_full, alpha=0.7, alpha_vec=batch.inv_m0, beta=0.5, c1=w)
+    assert not torch.equal(gf1, gf2) and (gf1 - gf2).abs().max().item() <= 2e-6 * max(1.0, gf2.abs().max().item())
 
 
 @pytest.mark.parametrize('prox_kind', ['tv', 'dncnn'])
@@ -455,7 +466,7 @@ def test_fused_engine_equals_unfused(prox_kind):
     eta = 2e3 if prox_kind == 'tv' else 1.0
     batch = CsmriBatch.synthetic(B, 256, 256, 0.2, 20.0, seed=13)
     for host in (False, True):
-        ef = SvrgEngine(batch, mk(), eta, T2, mb, seed=4)
+        ef = SvrgEngine(batch, mk(), eta, T2, mb, seed=4, fused=True)     # (automatic from B = 192 on)
         eu = SvrgEngine(batch, mk(), eta, T2, mb, seed=4, fused=False)
         assert ef.fused and not eu.fused
         idx = batch.draw_minibatches(steps, mb, seed=2) if host else None
@@ -464,11 +475,12 @@ def test_fused_engine_equals_unfused(prox_kind):
             eu.step(None if idx is None else idx[s])
         assert (ef.z - eu.z).abs().max().item() <= 5e-5 * max(1.0, eu.z.abs().max().item())
         assert np.abs(ef.psnr_trace() - eu.psnr_trace()).max() <= 0.01 + 1e-9
-    g = SvrgEngine(batch, mk(), eta, T2, mb, seed=4)
+    g = SvrgEngine(batch, mk(), eta, T2, mb, seed=4, fused=True)
     g.capture()
     g.run_outer(steps // T2)
-    e = SvrgEngine(batch, mk(), eta, T2, mb, seed=4)
+    e = SvrgEngine(batch, mk(), eta, T2, mb, seed=4, fused=True)
     for s in range(steps):
         e.step()
     assert torch.equal(g.z, e.z) and np.array_equal(g.psnr_trace(), e.psnr_trace())
     assert type(g.prox).__name__ != 'TVProx' or g.prox.t == e.prox.t == steps
+    assert not SvrgEngine(batch, mk(), eta, T2, mb).fused              # small batch: the streaming kernels

@@ -1,8 +1,11 @@
-# inner-iterations/s vs batch size (B in {1, 12, 120, 1024}); prints value, ms/step, roofline frac
-for B in 1 12 120 1024; do
-  S=20; [ $B -ge 120 ] && S=6; [ $B -ge 1024 ] && S=3
-  python bench.py --batch $B --steps $S --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('dncnn B=$B', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['launch_ms'])"
+#!/bin/bash
+# Throughput vs batch size (SURVEY 8d list) for configs 3 and 2 on one MI355X -> gpurun_out/batch_sweep.txt
+cd "$(dirname "$0")/.." && mkdir -p gpurun_out && : > gpurun_out/batch_sweep.txt
+for wl in dncnn tv; do
+  for b in 1 12 120 1024; do
+    steps=20; [ $wl = tv ] && steps=200; [ $b = 1024 ] && [ $wl = dncnn ] && steps=5
+    timeout -k 10 300 python bench.py --workload $wl --batch $b --steps $steps --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | \
+      python -c "import json,sys; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=l['roofline']; print('$wl', l['config']['batch_per_gpu'], l['value'], l['ms_per_step'], r['frac'], r.get('algorithmic_tflops',''))" >> gpurun_out/batch_sweep.txt
+  done
 done
-for B in 1 12 120 1024; do
-  python bench.py --workload tv --batch $B --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tv B=$B', d['value'], d['ms_per_step'], d['roofline']['frac'])"
-done
+cat gpurun_out/batch_sweep.txt

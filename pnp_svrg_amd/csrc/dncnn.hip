@@ -28,6 +28,7 @@
 #include "common.h"
 #include "f16x3.h"
 #include "wino4.h"
+#include "wino44.h"
 #include "tilewalk.h"
 #include "reduce.h"
 #include <vector>
@@ -654,6 +655,7 @@ struct pnp_dncnn_plan {
     int n_mid, H, W, batch, num_cu;
     float *w_first, *w_last, *wpack, *upack, *bias;   // device (upack: Winograd F(2,3)-transformed weights)
     float* upack4;                               // Winograd F(4,3)-transformed weights (dncnn_wino4.hip)
+    float* upack44;                              // Winograd F(4x4,3x3)-transformed weights (dncnn_wino44.hip)
     void* wpack16;                               // split-fp16 weight fragments (mode 3, dncnn_f16x3.hip)
     float* b_first;                              // [64] device, zeros unless pnp_dncnn_set_affine
     float b_last, slope;                         // last-layer bias, LeakyReLU slope (0 = ReLU)
@@ -712,6 +714,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
         // 0 = direct, 3 = opt-in split-fp16
         const char* ev = getenv("PNP_DNCNN_WINOGRAD");
         p->use_wino = ev ? atoi(ev) : 4;
+        if (p->use_wino == 5 && !wino44_supports(H, W)) p->use_wino = 4;
         if (p->use_wino == 4 && !wino4_supports(H, W)) p->use_wino = 1;
     }
     const size_t act_bytes = (size_t)batch * C * H * W * sizeof(float);
@@ -724,6 +727,12 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
         wino4_pack_weights(w_mid, n_mid, u4.data());
         if (e == hipSuccess) e = hipMalloc(&p->upack4, u4.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(p->upack4, u4.data(), u4.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+    {
+        std::vector<float> u44(wino44_weight_floats(n_mid));
+        wino44_pack_weights(w_mid, n_mid, u44.data());
+        if (e == hipSuccess) e = hipMalloc(&p->upack44, u44.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p->upack44, u44.data(), u44.size() * sizeof(float), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc(&p->bias, (size_t)n_mid * C * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->bias, b_mid, (size_t)n_mid * C * sizeof(float), hipMemcpyHostToDevice);
@@ -748,7 +757,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e != hipSuccess) {
         set_error(std::string("pnp_dncnn_plan_create: ") + hipGetErrorString(e));
         for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
-                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16, (void*)p->upack4})
+                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16, (void*)p->upack4, (void*)p->upack44})
             if (q) (void)hipFree(q);
         delete p;
         return PNP_ERR_HIP;
@@ -760,7 +769,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
 extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
     if (!p) return PNP_OK;
     for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
-                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16, (void*)p->upack4})
+                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16, (void*)p->upack4, (void*)p->upack44})
         (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -793,6 +802,10 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
         if (p->use_wino == 3) {
             const int rc = f16x3_layer(src, dst, (const unsigned char*)p->wpack16 + f16x3_weight_bytes(1) * (size_t)l,
                                        p->bias + (size_t)l * C, p->zeros, H, W, B, p->num_cu, l == p->n_mid - 1, p->slope, s);
+            if (rc != PNP_OK) return rc;
+        } else if (p->use_wino == 5) {
+            const int rc = wino44_layer(src, dst, p->upack44 + (size_t)l * wino44_weight_floats(1), p->bias + (size_t)l * C, p->zeros,
+                                        H, W, B, p->num_cu, p->slope, s);
             if (rc != PNP_OK) return rc;
         } else if (p->use_wino == 4) {
             const int rc = wino4_layer(src, dst, p->upack4 + (size_t)l * wino4_weight_floats(1), p->bias + (size_t)l * C, p->zeros,
@@ -839,8 +852,9 @@ extern "C" int pnp_dncnn_set_affine(pnp_dncnn_plan* p, const float* b_first, flo
 
 extern "C" int pnp_dncnn_set_winograd(pnp_dncnn_plan* p, int enable) {
     PNP_CHECK_ARG(p != nullptr, "null plan");
-    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 3 || enable == 4,
-                  "mode must be 0 (direct), 1 (Winograd F(2,3)), 3 (split-fp16) or 4 (Winograd F(4,3))");
+    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 3 || enable == 4 || enable == 5,
+                  "mode must be 0 (direct), 1 (Winograd F(2,3)), 3 (split-fp16), 4 (Winograd F(4,3)) or 5 (Winograd F(4x4,3x3))");
+    PNP_CHECK_ARG(!(enable == 5 && !wino44_supports(p->H, p->W)), "Winograd F(4x4,3x3) needs H % 8 == 0 and W % 64 == 0");
     PNP_CHECK_ARG(!(enable == 4 && !wino4_supports(p->H, p->W)), "Winograd F(4,3) needs H % 4 == 0 and W % 64 == 0");
     p->use_wino = enable;
     return PNP_OK;

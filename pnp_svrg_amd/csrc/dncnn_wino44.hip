@@ -1,0 +1,360 @@
+// dncnn_wino44.hip -- the 64 -> 64 channel 3x3 layer of the DnCNN prox (reference denoisers/DeepDenoisers/model/models.py:
+// 13-17: conv + BatchNorm + ReLU, BN folded by the caller) as the TWO-dimensional Winograd minimal-filtering algorithm
+// F(4x4, 3x3): per 4x4 output block and (cout, cin)
+//     V = B^T d B  (d = the 6x6 input patch)      U = G g G^T  (6x6 per (cout, cin), pre-transformed at plan creation)
+//     M_xi = sum_cin U_xi V_xi  (36 multiply-adds per cin for 16 outputs)          Y = A^T M A
+// i.e. ONE QUARTER of the direct form's matrix-core work (F(4,3) along x alone: one half); fp32 throughout.
+//
+// Organisation (one workgroup = 4 waves = one per SIMD, persistent over 8 x 64 output regions in the XCD-aware order):
+//   * the 36 transformed-domain products are 36 independent [64 cout] x [64 cin] x [32 blocks] GEMMs; wave wv owns output
+//     channels [16 wv, 16 wv + 16) and keeps ALL 36 x 2 accumulator quads (288 registers) for the region's 2 x 16 blocks;
+//   * input channels go by in chunks of 8: the chunk's (8+2) x 72 halo planes arrive by LDS-DMA, every thread transforms
+//     ONE (channel, block) patch -- the transform is shared by the four waves, i.e. by all 64 output channels -- and
+//     writes its 36 values to the V image [xi][row of blocks][k-row][block][k-step], from which a wave's B operands of
+//     one xi are a single conflict-free ds_read_b64 per block row;
+//   * transformed weights do not fit registers (36 x 64 x 64): they stream from L2 in MFMA operand order, one 16-byte
+//     load per lane and xi pair and chunk, each value used by two MFMAs (the two block rows);
+//   * software pipeline over chunks: while the MFMAs of chunk k run, the same wave transforms chunk k + 1 and the DMA of
+//     chunk k + 2 is in flight; one barrier per chunk.
+#include "common.h"
+#include "wino44.h"
+#include "tilewalk.h"
+#include <vector>
+#include <utility>
+
+namespace pnp {
+namespace w44 {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+constexpr int C = 64;
+constexpr int TR = 8, TC = 64;                        // output region: 2 x 16 blocks of 4 x 4
+constexpr int PR = TR + 2;                            // halo rows
+constexpr int PC = 72;                                // LDS row: image columns [tx0 - 4, tx0 + 68) = eighteen 16-byte chunks
+constexpr int PLANE = 768;                            // 720 payload + 48 pad: 0 mod 64 dwords (ds_read_b128 lane groups mix two planes)
+constexpr int KC = 8;                                 // input channels per chunk
+constexpr int NCH = C / KC;
+constexpr int DBUF = KC * PLANE;                      // 6144 floats = 24 DMA pieces of 1 KiB
+constexpr int PPW = DBUF / 256 / 4;                   // 6 pieces per wave
+constexpr int VPL = 256;                              // floats per xi plane of V: [2 block rows][4 k-rows][16 blocks][2 k-steps]
+constexpr int VBUF = 36 * VPL;
+constexpr int LDS_FLOATS = 2 * DBUF + 2 * VBUF;       // 30720 floats = 120 KiB
+constexpr int URING = 8;                              // weight loads in flight per lane
+constexpr unsigned DUMMY = 1u << 27;                  // descriptor flag: padding chunk of a plane
+
+// B^T of F(4,3) applied to six values
+__device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, float d4, float d5, float (&v)[6]) {
+    const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
+    const float t3 = d4 - d2, sd = d3 - d1;
+    v[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+    v[1] = t1 + t2;
+    v[2] = t1 - t2;
+    v[3] = __builtin_fmaf(2.f, sd, t3);
+    v[4] = __builtin_fmaf(-2.f, sd, t3);
+    v[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+}
+// A^T of F(4,3) applied to six values
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
+    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    y[0] = (m0 + s12) + s34;
+    y[1] = __builtin_fmaf(2.f, d34, d12);
+    y[2] = __builtin_fmaf(4.f, s34, s12);
+    y[3] = __builtin_fmaf(8.f, d34, d12) + m5;
+}
+
+// hand-issued MFMAs: the accumulator quad lives in AGPRs (AG) or VGPRs; the first product of a tile takes the constant-zero
+// SrcC form.  (Left to the compiler, all 72 quads are sent to the 256 AGPRs and the overflow is shuffled around.)
+template <bool AG> __device__ __forceinline__ void mfma(f32x4& acc, float w, float v) {
+    if (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(v));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(v));
+}
+template <bool AG> __device__ __forceinline__ void mfma_first(f32x4& acc, float w, float v) {
+    if (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(w), "v"(v));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(v));
+}
+constexpr int NQ_AGPR = 48;                                  // accumulator quads (of 72) kept in AGPRs: block row 0, and xi < 12 of row 1
+__host__ __device__ constexpr bool in_agpr(int g, int xi) { return g * 36 + xi < NQ_AGPR; }
+
+// ---- memory streams of the main loop ------------------------------------------------------------------------------------------
+// * LDS-DMA (activations): inline asm, invisible to the compiler's s_waitcnt insertion -- visible, it makes every LDS read
+//   after a DMA wait for vmcnt(0), which drains the weight ring at every step.  One hand-counted vmcnt wait per chunk
+//   (vector-memory operations leave the queue in issue order; sched_barriers pin the order of everything else around it).
+// * weights: plain loads, a ring of URING 16-byte values per lane; the compiler waits for them itself (its counts do not
+//   include the DMA pieces, so its waits are stricter than needed while pieces are in flight, never weaker).
+// * LDS: plain reads / writes, software-pipelined in the source (B operands one xi ahead, patch rows one slice ahead).
+// Order inside group G = 2p + q (one xi: 4 MFMAs) of a chunk:
+//     read B(G + 1) | q = 0: transform slice p (p < 12); q = 1: DMA piece p (p < PPW) | 4 MFMAs | q = 1: reload the ring slot
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) f32x2 lds_f2;
+typedef __attribute__((address_space(3))) f32x4 lds_f4;
+
+// one 1-KiB piece global -> LDS: lane's 16 bytes from rsrc.base + voff (an offset beyond num_records reads zeros)
+__device__ __forceinline__ void dma_piece_asm(unsigned voff, i32x4 rsrc, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsrc), "s"(lds_byte_addr) : "memory");
+}
+
+struct Patch {
+    f32x2 a; f32x4 m; f32x2 e;                                 // one patch row in flight: LDS columns 4tc + 2..3, 4..7, 8..9
+    float t[6][6];
+};
+struct Ctx {
+    f32x4 acc[2][36];
+    f32x4 ur[URING];
+    Patch P;
+    f32x2 b[2][2];                                             // B operands of the current / next xi: [parity][block row]
+    const lds_f* dsrc[2];                                      // this lane's patch in the two d buffers
+    lds_f* vdst[2];                                            // its V item in the two V buffers
+    const lds_f* vsrc0[2];                                     // its B operands (block row 0 / 1) in the two V buffers;
+    const lds_f* vsrc1[2];                                     //   separate, laundered bases: no ds_read2st64_b64 merging
+    const __attribute__((address_space(1))) f32x4* up;         // weight stream of this lane
+};
+// patch row R of d buffer DPAR; all ten floats are "used" so that the reads stay one conflict-free ds_read_b128 and two
+// ds_read_b64 (narrowed to the six needed values they become three 4-way bank-conflicting ds_read2_b32)
+template <int DPAR, int R> __device__ __forceinline__ void patch_load(Ctx& c) {
+    const lds_f* row = c.dsrc[DPAR] + R * PC;                    // 16-byte aligned
+    c.P.a = *(const lds_f2*)(row + 2);
+    c.P.m = *(const lds_f4*)(row + 4);
+    c.P.e = *(const lds_f2*)(row + 8);
+}
+// transform slice SL of the patch (d buffer DPAR -> V buffer DPAR): 0..5 = row transforms (row SL + 1 is requested first),
+// 6..11 = column transforms and the six V values of column SL - 6
+template <int DPAR, int SL> __device__ __forceinline__ void patch_slice(Ctx& c) {
+    Patch& P = c.P;
+    if constexpr (SL < 6) {
+        const float d0 = P.a.y, d1 = P.m.x, d2 = P.m.y, d3 = P.m.z, d4 = P.m.w, d5 = P.e.x;
+        asm volatile("" :: "v"(P.a.x), "v"(P.e.y));
+        if constexpr (SL + 1 < 6) patch_load<DPAR, SL + 1>(c);
+        bt6(d0, d1, d2, d3, d4, d5, P.t[SL]);
+    } else {
+        constexpr int x = SL - 6;
+        float v[6];
+        bt6(P.t[0][x], P.t[1][x], P.t[2][x], P.t[3][x], P.t[4][x], P.t[5][x], v);
+#pragma unroll
+        for (int y = 0; y < 6; ++y) c.vdst[DPAR][(y * 6 + x) * VPL] = v[y];
+    }
+}
+template <int VPAR, int XI> __device__ __forceinline__ void b_load(Ctx& c) {
+    c.b[XI & 1][0] = *(const lds_f2*)(c.vsrc0[VPAR] + XI * VPL);
+    c.b[XI & 1][1] = *(const lds_f2*)(c.vsrc1[VPAR] + XI * VPL);
+}
+
+// group (K, P, Q) of the main loop; dma(piece) issues DMA piece `piece` of chunk K + 2
+template <int K, int P, int Q, typename DMA> __device__ __forceinline__ void group(Ctx& c, DMA&& dma) {
+    constexpr int XI = 2 * P + Q, SQ = K * 18 + P;
+    constexpr int VPAR = K & 1, DPAR = (K + 1) & 1;
+    const f32x2 b0 = c.b[XI & 1][0], b1 = c.b[XI & 1][1];
+    if constexpr (XI + 1 < 36) b_load<VPAR, XI + 1>(c);
+    const f32x4 u = c.ur[SQ % URING];
+    if constexpr (Q == 0) {
+        if constexpr (P < 12) patch_slice<DPAR, P>(c);
+    } else {
+        if constexpr (P < PPW) dma(P);
+    }
+    const float u0 = Q ? u.z : u.x, u1 = Q ? u.w : u.y;
+    asm volatile("s_nop 1" ::: "memory");
+    if constexpr (K == 0) {
+        mfma_first<in_agpr(0, XI)>(c.acc[0][XI], u0, b0.x);
+        mfma_first<in_agpr(1, XI)>(c.acc[1][XI], u0, b1.x);
+    } else {
+        mfma<in_agpr(0, XI)>(c.acc[0][XI], u0, b0.x);
+        mfma<in_agpr(1, XI)>(c.acc[1][XI], u0, b1.x);
+    }
+    mfma<in_agpr(0, XI)>(c.acc[0][XI], u1, b0.y);
+    mfma<in_agpr(1, XI)>(c.acc[1][XI], u1, b1.y);
+    if constexpr (Q == 1) c.ur[SQ % URING] = c.up[((SQ + URING) % (NCH * 18)) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int K, typename DMA, int... G> __device__ __forceinline__ void chunk_groups(Ctx& c, DMA&& dma, std::integer_sequence<int, G...>) {
+    (group<K, G / 2, G % 2>(c, dma), ...);
+}
+// chunk K of a tile: MFMAs on V buffer K & 1, transform of chunk K + 1, DMA of chunk K + 2
+template <int K, typename DMA> __device__ __forceinline__ void chunk(Ctx& c, DMA&& dma) {
+    patch_load<(K + 1) & 1, 0>(c);
+    b_load<K & 1, 0>(c);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_groups<K>(c, dma, std::make_integer_sequence<int, 36>{});
+    // this chunk's DMA pieces (issued in steps 0 .. PPW - 1, before more than URING weight loads) have landed
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(URING) : "memory");
+    __syncthreads();
+}
+template <typename MK, int... K> __device__ __forceinline__ void all_chunks(Ctx& c, MK&& mk, std::integer_sequence<int, K...>) {
+    (chunk<K>(c, mk(std::integral_constant<int, K>{})), ...);
+}
+
+// the first chunk of a workgroup's first tile, outside the pipeline
+__device__ __forceinline__ void transform0(const float* dsrc, float* vdst) {
+    float t[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const float* row = dsrc + r * PC;                         // LDS column 4 tc of patch row r
+        bt6(row[3], row[4], row[5], row[6], row[7], row[8], t[r]);
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+        float v[6];
+        bt6(t[0][x], t[1][x], t[2][x], t[3][x], t[4][x], t[5][x], v);
+#pragma unroll
+        for (int y = 0; y < 6; ++y) vdst[(y * 6 + x) * VPL] = v[y];
+    }
+}
+
+template <bool LEAKY>
+__global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__ in, float* __restrict__ out,
+                                                       const float4* __restrict__ upack, const float* __restrict__ bias,
+                                                       int H, int W, int ntiles, float slope) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
+
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[16 * wv + 4 * (lane >> 4) + r];
+
+    // transform item of this thread: block (g, tc), chunk channel 2 wv + j  (k-row wv, k-step j of the MFMA B operand)
+    const int tc = lane & 15, j = (lane >> 4) & 1, g = lane >> 5;
+    const int d_off = 4 * ((2 * wv + j) * (PLANE / 4) + g * PC + tc);               // 16-byte aligned
+    const int v_off = g * 128 + wv * 32 + tc * 2 + j;
+
+    // DMA piece descriptors: bits 0..26 = element offset of the lane's 16-byte chunk inside the chunk's 8 channel planes,
+    // bit 27 = padding, bits 28..31 = which image edge would put the chunk outside
+    unsigned pdesc[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = (wv + 4 * i) * 64 + lane;
+        const int c = q / (PLANE / 4), r = q - c * (PLANE / 4);
+        const int ry = r / 18, cx4 = 4 * (r - ry * 18);
+        const unsigned edge = (ry == 0 ? 1u : 0u) | (ry == PR - 1 ? 2u : 0u) | (cx4 == 0 ? 4u : 0u) | (cx4 == TC + 4 ? 8u : 0u);
+        pdesc[i] = r < PR * 18 ? ((unsigned)((c * H + ry) * W + cx4) | (edge << 28)) : DUMMY;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    // piece i of chunk k of tile t -> d buffer `buf`; t == ntiles: zeros
+    auto dma_piece = [&](int t, int k, int buf, int i) {
+        const int b = t / tiles_per_img, t2 = t - b * tiles_per_img;
+        const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
+        const size_t base = (size_t)in + 4 * ((((size_t)b * C + k * KC) * H + ty0 - 1) * (size_t)W + tx0 - 4);
+        i32x4 rs;
+        rs.x = (int)(unsigned)base; rs.y = (int)(unsigned)(base >> 32) & 0xFFFF; rs.z = (int)0x80000000u; rs.w = 0x00020000;
+        const unsigned bad = t < ntiles ? ((((ty0 == 0 ? 1u : 0u) | (ty0 + TR == H ? 2u : 0u) | (tx0 == 0 ? 4u : 0u) | (tx0 + TC == W ? 8u : 0u)) << 28) | DUMMY)
+                                        : 0xFFFFFFFFu;
+        const unsigned voff = (pdesc[i] & bad) == 0u ? 4u * (pdesc[i] & 0x07FFFFFFu) : 0x80000000u;
+        dma_piece_asm(voff, rs, lds0 + 4u * (unsigned)(buf * DBUF + (wv + 4 * i) * 256));
+    };
+
+    float* const dbuf = lds;
+    float* const vbuf = lds + 2 * DBUF;
+
+    Ctx c;
+    lds_f* const ldsp = (lds_f*)lds;
+    c.dsrc[0] = ldsp + d_off;                     c.dsrc[1] = ldsp + DBUF + d_off;
+    c.vdst[0] = ldsp + 2 * DBUF + v_off;          c.vdst[1] = ldsp + 2 * DBUF + VBUF + v_off;
+    c.vsrc0[0] = ldsp + 2 * DBUF + 2 * lane;      c.vsrc0[1] = ldsp + 2 * DBUF + VBUF + 2 * lane;
+    c.vsrc1[0] = c.vsrc0[0] + 128;                c.vsrc1[1] = c.vsrc0[1] + 128;
+    asm volatile("" : "+v"(c.vsrc1[0]), "+v"(c.vsrc1[1]));
+    // transformed weights: the same stream of NCH x 18 16-byte loads per lane for every tile, kept URING loads ahead
+    c.up = (const __attribute__((address_space(1))) f32x4*)upack + (size_t)(wv * NCH * 18) * 64 + lane;
+
+    const TileWalk tw_ = tile_walk(ntiles);
+    int tile = tw_.first;
+    const int limit = tw_.limit < ntiles ? tw_.limit : ntiles;
+    {
+        const int t0 = tile < limit ? tile : ntiles;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(t0, 0, 0, i);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_piece(t0, 1, 1, i);
+#pragma unroll
+        for (int i = 0; i < URING; ++i) c.ur[i] = c.up[i * 64];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        transform0(dbuf + d_off, vbuf + v_off);
+        __syncthreads();
+    }
+
+    for (; tile < limit; tile += tw_.step) {
+        asm volatile("" : "+v"(c.up));                                          // the weight loads stay inside the tile loop
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
+        const int ntile = tile + tw_.step < limit ? tile + tw_.step : ntiles;      // ntiles = "none": zeros
+
+        all_chunks(c, [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            // chunk K + 2 -> the d buffer chunk K was transformed from
+            return [&, tile, ntile](int piece) {
+                if (K + 2 < NCH) dma_piece(tile, K + 2, K & 1, piece);
+                else dma_piece(ntile, K + 2 - NCH, K & 1, piece);
+            };
+        }, std::make_integer_sequence<int, NCH>{});
+
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA write -> VALU read distance
+        // epilogue: Y = A^T M A, bias, ReLU; a lane holds block (g2, tc) of channels 16 wv + 4 (lane >> 4) + i
+        float* ob = out + ((size_t)b * C + 16 * wv + 4 * (lane >> 4)) * H * W + (size_t)ty0 * W + tx0 + 4 * tc;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s[6][4];                                  // s[x][r]: A^T along y of column x
+#pragma unroll
+                for (int x = 0; x < 6; ++x)
+                    at6(c.acc[g2][x][i], c.acc[g2][6 + x][i], c.acc[g2][12 + x][i], c.acc[g2][18 + x][i], c.acc[g2][24 + x][i],
+                        c.acc[g2][30 + x][i], s[x]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float y[4];
+                    at6(s[0][r], s[1][r], s[2][r], s[3][r], s[4][r], s[5][r], y);
+                    float4 v;
+                    v.x = y[0] + bv[i]; v.y = y[1] + bv[i]; v.z = y[2] + bv[i]; v.w = y[3] + bv[i];
+                    v.x = v.x > 0.f ? v.x : (LEAKY ? slope * v.x : 0.f);
+                    v.y = v.y > 0.f ? v.y : (LEAKY ? slope * v.y : 0.f);
+                    v.z = v.z > 0.f ? v.z : (LEAKY ? slope * v.z : 0.f);
+                    v.w = v.w > 0.f ? v.w : (LEAKY ? slope * v.w : 0.f);
+                    *reinterpret_cast<float4*>(ob + (size_t)i * H * W + (4 * g2 + r) * W) = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace w44
+
+bool wino44_supports(int H, int W) { return H % w44::TR == 0 && W % w44::TC == 0; }
+
+size_t wino44_weight_floats(int n_mid) { return (size_t)n_mid * 4 * w44::NCH * 18 * 64 * 4; }
+
+// w_mid [n_mid][64][64][3][3] (BN folded) -> upack[l][wv][chunk k][xi pair p][lane][e]:  xi = 2 p + (e >> 1), k-step j = e & 1,
+// U_xi[cout = 16 wv + (lane & 15)][cin = 8 k + 2 (lane >> 4) + j],  U = G g G^T,  xi = 6 xi_y + xi_x
+void wino44_pack_weights(const float* w_mid, int n_mid, float* out) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (int l = 0; l < n_mid; ++l)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int k = 0; k < w44::NCH; ++k)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 2; ++j) {
+                        const int cout = 16 * wv + (lane & 15), cin = w44::KC * k + 2 * (lane >> 4) + j;
+                        const float* g = w_mid + (((size_t)l * w44::C + cout) * w44::C + cin) * 9;
+                        for (int xy = 0; xy < 6; ++xy)
+                            for (int xx = 0; xx < 6; ++xx) {
+                                double u = 0;
+                                for (int dy = 0; dy < 3; ++dy)
+                                    for (int dx = 0; dx < 3; ++dx) u += G[xy][dy] * G[xx][dx] * (double)g[dy * 3 + dx];
+                                const int xi = 6 * xy + xx, p = xi >> 1, e = 2 * (xi & 1) + j;
+                                out[((((size_t)(l * 4 + wv) * w44::NCH + k) * 18 + p) * 64 + lane) * 4 + e] = (float)u;
+                            }
+                    }
+}
+
+int wino44_layer(const float* in, float* out, const float* upack_layer, const float* bias, const float* zeros, int H, int W,
+                 int batch, int num_cu, float slope, hipStream_t s) {
+    const int ntiles = batch * (H / w44::TR) * (W / w44::TC);
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    if (slope != 0.f)
+        w44::k_mid_wino44<true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, slope);
+    else
+        w44::k_mid_wino44<false><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+
+}  // namespace pnp

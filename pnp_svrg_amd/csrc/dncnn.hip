@@ -897,6 +897,26 @@ extern "C" int pnp_dncnn_debug_clock(pnp_dncnn_plan* p, int reps, double* cycles
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
     unsigned long long* d = nullptr;
     PNP_CHECK_HIP(hipMalloc(&d, (size_t)grid * 5 * sizeof(unsigned long long)));
+    if (p->use_wino == 5) {                                     // F(4x4,3x3): 8 x 64 regions, 4 stamps per workgroup
+        const int nt5 = p->batch * (p->H / 8) * (p->W / 64), g5 = nt5 < p->num_cu ? nt5 : p->num_cu;
+        const int rc = wino44_debug_clock(p->act0, p->act1, p->upack44, p->bias, p->H, p->W, p->batch, p->num_cu, reps, d, s);
+        if (rc != PNP_OK) { (void)hipFree(d); return rc; }
+        std::vector<unsigned long long> h5((size_t)g5 * 4);
+        hipError_t e5 = hipMemcpyAsync(h5.data(), d, h5.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+        if (e5 == hipSuccess) e5 = hipStreamSynchronize(s);
+        (void)hipFree(d);
+        PNP_CHECK_HIP(e5);
+        std::vector<double> c5(g5), r5(g5);
+        double wsum = 0, esum = 0;
+        for (int i = 0; i < g5; ++i) { c5[i] = (double)h5[4 * i]; r5[i] = (double)h5[4 * i + 1]; wsum += h5[4 * i + 2]; esum += h5[4 * i + 3]; }
+        if (getenv("PNP_DEBUG_STAMPS"))
+            fprintf(stderr, "[k_mid_wino44 stamps] mean cycles per WG: chunk-end wait + barrier %.0f  epilogue %.0f\n", wsum / g5, esum / g5);
+        std::sort(c5.begin(), c5.end());
+        std::sort(r5.begin(), r5.end());
+        *cycles = c5[g5 / 2];
+        *ref_ticks = r5[g5 / 2];
+        return PNP_OK;
+    }
     if (p->use_wino == 3) {                                     // split-fp16 layer: whole-workgroup cycles and reference ticks
         // (the activation buffers keep what the last forward pass left in them: realistic operands, realistic power)
         for (int i = 0; i < reps; ++i) {

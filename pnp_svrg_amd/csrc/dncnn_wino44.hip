@@ -21,6 +21,7 @@
 #include "tilewalk.h"
 #include <vector>
 #include <utility>
+#include <cstdlib>
 
 namespace pnp {
 namespace w44 {
@@ -55,25 +56,32 @@ __device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, floa
     v[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
 }
 // A^T of F(4,3) applied to six values
-__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
-    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+template <typename T> __device__ __forceinline__ void at6(T m0, T m1, T m2, T m3, T m4, T m5, T (&y)[4]) {
+    const T s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
     y[0] = (m0 + s12) + s34;
-    y[1] = __builtin_fmaf(2.f, d34, d12);
-    y[2] = __builtin_fmaf(4.f, s34, s12);
-    y[3] = __builtin_fmaf(8.f, d34, d12) + m5;
+    y[1] = 2.f * d34 + d12;                                 // contracted to (packed) fma
+    y[2] = 4.f * s34 + s12;
+    y[3] = (8.f * d34 + d12) + m5;
 }
 
 // hand-issued MFMAs: the accumulator quad lives in AGPRs (AG) or VGPRs; the first product of a tile takes the constant-zero
 // SrcC form.  (Left to the compiler, all 72 quads are sent to the 256 AGPRs and the overflow is shuffled around.)
+// hipcc does not look inside inline asm, so its hazard recognizer protects nothing here: if register pressure makes it
+// split an accumulator's live range, the copy it puts next to the MFMA reads the 4th register (written by the last pass)
+// stale.  Wait states inside every statement cost 30 cycles per MFMA, so instead the kernel keeps the pressure low enough
+// that no accumulator is ever moved (all 256 AGPRs are accumulators, the epilogue reads them in small batches) and
+// tests/test_cpu_host.py::test_w44_accumulators_untouched checks the generated code for it.
+#define PNP_MFMA_PRE ""
+#define PNP_MFMA_POST ""
 template <bool AG> __device__ __forceinline__ void mfma(f32x4& acc, float w, float v) {
-    if (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(v));
-    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(v));
+    if (AG) asm volatile(PNP_MFMA_PRE "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" PNP_MFMA_POST : "+a"(acc) : "v"(w), "v"(v));
+    else asm volatile(PNP_MFMA_PRE "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" PNP_MFMA_POST : "+v"(acc) : "v"(w), "v"(v));
 }
 template <bool AG> __device__ __forceinline__ void mfma_first(f32x4& acc, float w, float v) {
-    if (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(acc) : "v"(w), "v"(v));
-    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(v));
+    if (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" PNP_MFMA_POST : "=&a"(acc) : "v"(w), "v"(v));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" PNP_MFMA_POST : "=&v"(acc) : "v"(w), "v"(v));
 }
-constexpr int NQ_AGPR = 48;                                  // accumulator quads (of 72) kept in AGPRs: block row 0, and xi < 12 of row 1
+constexpr int NQ_AGPR = 64;                                  // accumulator quads (of 72) kept in AGPRs: block row 0, and xi < 28 of row 1
 __host__ __device__ constexpr bool in_agpr(int g, int xi) { return g * 36 + xi < NQ_AGPR; }
 
 // ---- memory streams of the main loop ------------------------------------------------------------------------------------------
@@ -98,6 +106,7 @@ __device__ __forceinline__ void dma_piece_asm(unsigned voff, i32x4 rsrc, unsigne
 struct Patch {
     f32x2 a; f32x4 m; f32x2 e;                                 // one patch row in flight: LDS columns 4tc + 2..3, 4..7, 8..9
     float t[6][6];
+    float v[6];                                                // one transformed column on its way to the V image
 };
 struct Ctx {
     f32x4 acc[2][36];
@@ -110,77 +119,132 @@ struct Ctx {
     const lds_f* vsrc1[2];                                     //   separate, laundered bases: no ds_read2st64_b64 merging
     const __attribute__((address_space(1))) f32x4* up;         // weight stream of this lane
 };
-// patch row R of d buffer DPAR; all ten floats are "used" so that the reads stay one conflict-free ds_read_b128 and two
-// ds_read_b64 (narrowed to the six needed values they become three 4-way bank-conflicting ds_read2_b32)
-template <int DPAR, int R> __device__ __forceinline__ void patch_load(Ctx& c) {
+// One LDS read beside an f32 MFMA is free, two in the same gap cost about an MFMA (tools/microbench/mfma_f32_fillers.hip),
+// and vector-ALU work is cheapest in blocks; so a step (two xi = 8 MFMAs) has fixed slots, pinned by sched_barriers:
+//     M1 | B(xi1)[0] | M2 | B(xi1)[1] | M3 | VALU block of transform slice p | M4 | slice LDS op 1 |
+//     M5 | B(xi0')[0] | M6 | B(xi0')[1] | M7 | DMA piece p, slice LDS op 2 | M8 | slice LDS op 3, ring reload
+#define PNP_SLOT() __builtin_amdgcn_sched_barrier(0)
+
+// patch row R of d buffer DPAR, in two halves; all ten floats are "used" (patch_rows) so that the reads stay one
+// conflict-free ds_read_b128 and two ds_read_b64 (narrowed to the six needed values they become three 4-way
+// bank-conflicting ds_read2_b32)
+template <int DPAR, int R, int HALF> __device__ __forceinline__ void patch_load(Ctx& c) {
     const lds_f* row = c.dsrc[DPAR] + R * PC;                    // 16-byte aligned
-    c.P.a = *(const lds_f2*)(row + 2);
-    c.P.m = *(const lds_f4*)(row + 4);
-    c.P.e = *(const lds_f2*)(row + 8);
+    if (HALF == 0) { c.P.a = *(const lds_f2*)(row + 2); c.P.e = *(const lds_f2*)(row + 8); }
+    else c.P.m = *(const lds_f4*)(row + 4);
 }
-// transform slice SL of the patch (d buffer DPAR -> V buffer DPAR): 0..5 = row transforms (row SL + 1 is requested first),
-// 6..11 = column transforms and the six V values of column SL - 6
-template <int DPAR, int SL> __device__ __forceinline__ void patch_slice(Ctx& c) {
+// transform slice SL of the patch (d buffer DPAR -> V buffer DPAR): 0..5 = row transforms, 6..11 = column transforms;
+// the six V values of column SL - 6 wait in P.v for their write slots
+template <int SL> __device__ __forceinline__ void slice_valu(Ctx& c) {
     Patch& P = c.P;
     if constexpr (SL < 6) {
-        const float d0 = P.a.y, d1 = P.m.x, d2 = P.m.y, d3 = P.m.z, d4 = P.m.w, d5 = P.e.x;
         asm volatile("" :: "v"(P.a.x), "v"(P.e.y));
-        if constexpr (SL + 1 < 6) patch_load<DPAR, SL + 1>(c);
-        bt6(d0, d1, d2, d3, d4, d5, P.t[SL]);
-    } else {
+        bt6(P.a.y, P.m.x, P.m.y, P.m.z, P.m.w, P.e.x, P.t[SL]);
+    } else if constexpr (SL < 12) {
         constexpr int x = SL - 6;
-        float v[6];
-        bt6(P.t[0][x], P.t[1][x], P.t[2][x], P.t[3][x], P.t[4][x], P.t[5][x], v);
-#pragma unroll
-        for (int y = 0; y < 6; ++y) c.vdst[DPAR][(y * 6 + x) * VPL] = v[y];
+        bt6(P.t[0][x], P.t[1][x], P.t[2][x], P.t[3][x], P.t[4][x], P.t[5][x], P.v);
     }
 }
-template <int VPAR, int XI> __device__ __forceinline__ void b_load(Ctx& c) {
-    c.b[XI & 1][0] = *(const lds_f2*)(c.vsrc0[VPAR] + XI * VPL);
-    c.b[XI & 1][1] = *(const lds_f2*)(c.vsrc1[VPAR] + XI * VPL);
+// LDS operation N (0..2) of slice SL: the next patch row's reads (SL < 5) or two of the six V writes (6 <= SL < 12)
+template <int DPAR, int SL, int N> __device__ __forceinline__ void slice_lds(Ctx& c) {
+    if constexpr (SL < 5) {
+        if constexpr (N < 2) patch_load<DPAR, SL + 1, N>(c);
+    } else if constexpr (SL >= 6 && SL < 12) {
+        constexpr int x = SL - 6;
+        c.vdst[DPAR][((2 * N) * 6 + x) * VPL] = c.P.v[2 * N];
+        c.vdst[DPAR][((2 * N + 1) * 6 + x) * VPL] = c.P.v[2 * N + 1];
+    }
+}
+template <int VPAR, int XI, int G> __device__ __forceinline__ void b_load(Ctx& c) {
+    if (G == 0) c.b[XI & 1][0] = *(const lds_f2*)(c.vsrc0[VPAR] + XI * VPL);
+    else c.b[XI & 1][1] = *(const lds_f2*)(c.vsrc1[VPAR] + XI * VPL);
+}
+template <int K, int XI, int G> __device__ __forceinline__ void mfma_j0(Ctx& c, float u, float b) {
+    if constexpr (K == 0) mfma_first<in_agpr(G, XI)>(c.acc[G][XI], u, b);
+    else mfma<in_agpr(G, XI)>(c.acc[G][XI], u, b);
 }
 
-// group (K, P, Q) of the main loop; dma(piece) issues DMA piece `piece` of chunk K + 2
-template <int K, int P, int Q, typename DMA> __device__ __forceinline__ void group(Ctx& c, DMA&& dma) {
-    constexpr int XI = 2 * P + Q, SQ = K * 18 + P;
+// step (K, P) of the main loop: xi = 2P, 2P + 1; dma(piece) issues DMA piece `piece` of chunk K + 2
+// VAR (diagnostic): 5 = the order of the first, compiler-scheduled version (everything in front of each xi's four MFMAs)
+template <int K, int P, int VAR, typename DMA> __device__ __forceinline__ void step(Ctx& c, DMA&& dma) {
+    constexpr int X0 = 2 * P, X1 = 2 * P + 1, SQ = K * 18 + P;
     constexpr int VPAR = K & 1, DPAR = (K + 1) & 1;
-    const f32x2 b0 = c.b[XI & 1][0], b1 = c.b[XI & 1][1];
-    if constexpr (XI + 1 < 36) b_load<VPAR, XI + 1>(c);
     const f32x4 u = c.ur[SQ % URING];
-    if constexpr (Q == 0) {
-        if constexpr (P < 12) patch_slice<DPAR, P>(c);
-    } else {
-        if constexpr (P < PPW) dma(P);
+    if constexpr (VAR == 5) {
+        {
+            const f32x2 b0 = c.b[0][0], b1 = c.b[0][1];
+            b_load<VPAR, X1, 0>(c); b_load<VPAR, X1, 1>(c);
+            slice_valu<P>(c); slice_lds<DPAR, P, 0>(c); slice_lds<DPAR, P, 1>(c); slice_lds<DPAR, P, 2>(c);
+            asm volatile("s_nop 1" ::: "memory");
+            mfma_j0<K, X0, 0>(c, u.x, b0.x);
+            mfma_j0<K, X0, 1>(c, u.x, b1.x);
+            mfma<in_agpr(0, X0)>(c.acc[0][X0], u.y, b0.y);
+            mfma<in_agpr(1, X0)>(c.acc[1][X0], u.y, b1.y);
+            PNP_SLOT();
+        }
+        {
+            const f32x2 b0 = c.b[1][0], b1 = c.b[1][1];
+            if constexpr (X1 + 1 < 36) { b_load<VPAR, X1 + 1, 0>(c); b_load<VPAR, X1 + 1, 1>(c); }
+            if constexpr (P < PPW) dma(P);
+            asm volatile("s_nop 1" ::: "memory");
+            mfma_j0<K, X1, 0>(c, u.z, b0.x);
+            mfma_j0<K, X1, 1>(c, u.z, b1.x);
+            mfma<in_agpr(0, X1)>(c.acc[0][X1], u.w, b0.y);
+            mfma<in_agpr(1, X1)>(c.acc[1][X1], u.w, b1.y);
+            c.ur[SQ % URING] = c.up[((SQ + URING) % (NCH * 18)) * 64];
+            PNP_SLOT();
+        }
+        return;
     }
-    const float u0 = Q ? u.z : u.x, u1 = Q ? u.w : u.y;
-    asm volatile("s_nop 1" ::: "memory");
-    if constexpr (K == 0) {
-        mfma_first<in_agpr(0, XI)>(c.acc[0][XI], u0, b0.x);
-        mfma_first<in_agpr(1, XI)>(c.acc[1][XI], u0, b1.x);
-    } else {
-        mfma<in_agpr(0, XI)>(c.acc[0][XI], u0, b0.x);
-        mfma<in_agpr(1, XI)>(c.acc[1][XI], u0, b1.x);
-    }
-    mfma<in_agpr(0, XI)>(c.acc[0][XI], u1, b0.y);
-    mfma<in_agpr(1, XI)>(c.acc[1][XI], u1, b1.y);
-    if constexpr (Q == 1) c.ur[SQ % URING] = c.up[((SQ + URING) % (NCH * 18)) * 64];
-    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 b0 = c.b[0][0], b1 = c.b[0][1];
+    mfma_j0<K, X0, 0>(c, u.x, b0.x);                 PNP_SLOT();          // M1
+    if constexpr (VAR != 13 && VAR != 15) b_load<VPAR, X1, 0>(c);
+    PNP_SLOT();
+    mfma_j0<K, X0, 1>(c, u.x, b1.x);                 PNP_SLOT();          // M2
+    if constexpr (VAR != 13 && VAR != 15) b_load<VPAR, X1, 1>(c);
+    PNP_SLOT();
+    mfma<in_agpr(0, X0)>(c.acc[0][X0], u.y, b0.y);   PNP_SLOT();          // M3
+    if constexpr (VAR != 10 && VAR != 15) slice_valu<P>(c);
+    PNP_SLOT();
+    mfma<in_agpr(1, X0)>(c.acc[1][X0], u.y, b1.y);   PNP_SLOT();          // M4
+    if constexpr (VAR != 14 && VAR != 15) slice_lds<DPAR, P, 0>(c);
+    PNP_SLOT();
+    const f32x2 c0 = c.b[1][0], c1 = c.b[1][1];
+    mfma_j0<K, X1, 0>(c, u.z, c0.x);                 PNP_SLOT();          // M5
+    if constexpr (X1 + 1 < 36 && VAR != 13 && VAR != 15) b_load<VPAR, X1 + 1, 0>(c);
+    PNP_SLOT();
+    mfma_j0<K, X1, 1>(c, u.z, c1.x);                 PNP_SLOT();          // M6
+    if constexpr (X1 + 1 < 36 && VAR != 13 && VAR != 15) b_load<VPAR, X1 + 1, 1>(c);
+    PNP_SLOT();
+    mfma<in_agpr(0, X1)>(c.acc[0][X1], u.w, c0.y);   PNP_SLOT();          // M7
+    if constexpr (P < PPW && VAR != 11 && VAR != 15) dma(P);
+    if constexpr (VAR != 14 && VAR != 15) slice_lds<DPAR, P, 1>(c);
+    PNP_SLOT();
+    mfma<in_agpr(1, X1)>(c.acc[1][X1], u.w, c1.y);   PNP_SLOT();          // M8
+    if constexpr (VAR != 14 && VAR != 15) slice_lds<DPAR, P, 2>(c);
+    if constexpr (VAR != 12 && VAR != 15) c.ur[SQ % URING] = c.up[((SQ + URING) % (NCH * 18)) * 64];
+    PNP_SLOT();
 }
-template <int K, typename DMA, int... G> __device__ __forceinline__ void chunk_groups(Ctx& c, DMA&& dma, std::integer_sequence<int, G...>) {
-    (group<K, G / 2, G % 2>(c, dma), ...);
+template <int K, int VAR, typename DMA, int... P> __device__ __forceinline__ void chunk_steps(Ctx& c, DMA&& dma, std::integer_sequence<int, P...>) {
+    (step<K, P, VAR>(c, dma), ...);
 }
 // chunk K of a tile: MFMAs on V buffer K & 1, transform of chunk K + 1, DMA of chunk K + 2
-template <int K, typename DMA> __device__ __forceinline__ void chunk(Ctx& c, DMA&& dma) {
-    patch_load<(K + 1) & 1, 0>(c);
-    b_load<K & 1, 0>(c);
-    __builtin_amdgcn_sched_barrier(0);
-    chunk_groups<K>(c, dma, std::make_integer_sequence<int, 36>{});
+template <int K, bool STAMP, int VAR, typename DMA> __device__ __forceinline__ void chunk(Ctx& c, DMA&& dma, unsigned long long& t_wait) {
+    patch_load<(K + 1) & 1, 0, 0>(c);
+    patch_load<(K + 1) & 1, 0, 1>(c);
+    b_load<K & 1, 0, 0>(c);
+    b_load<K & 1, 0, 1>(c);
+    PNP_SLOT();
+    chunk_steps<K, VAR>(c, dma, std::make_integer_sequence<int, 18>{});
+    unsigned long long ta = 0;
+    if (STAMP) ta = __builtin_amdgcn_s_memtime();
     // this chunk's DMA pieces (issued in steps 0 .. PPW - 1, before more than URING weight loads) have landed
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(URING) : "memory");
     __syncthreads();
+    if (STAMP) t_wait += __builtin_amdgcn_s_memtime() - ta;
 }
-template <typename MK, int... K> __device__ __forceinline__ void all_chunks(Ctx& c, MK&& mk, std::integer_sequence<int, K...>) {
-    (chunk<K>(c, mk(std::integral_constant<int, K>{})), ...);
+template <bool STAMP, int VAR, typename MK, int... K> __device__ __forceinline__ void all_chunks(Ctx& c, MK&& mk, unsigned long long& t_wait, std::integer_sequence<int, K...>) {
+    (chunk<K, STAMP, VAR>(c, mk(std::integral_constant<int, K>{}), t_wait), ...);
 }
 
 // the first chunk of a workgroup's first tile, outside the pipeline
@@ -200,10 +264,13 @@ __device__ __forceinline__ void transform0(const float* dsrc, float* vdst) {
     }
 }
 
-template <bool LEAKY>
+// STAMP: diagnostic build only (wino44_debug_clock): s_memtime / s_memrealtime around the tile loop, the chunk-end waits and
+// the epilogue; the stamps go to their own buffer
+template <bool LEAKY, bool STAMP = false, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__ in, float* __restrict__ out,
                                                        const float4* __restrict__ upack, const float* __restrict__ bias,
-                                                       int H, int W, int ntiles, float slope) {
+                                                       int H, int W, int ntiles, float slope,
+                                                       unsigned long long* __restrict__ stamps = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
@@ -272,47 +339,87 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
         __syncthreads();
     }
 
+    unsigned long long t0 = 0, r0 = 0, t_wait = 0, t_epi = 0;
+    if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (; tile < limit; tile += tw_.step) {
         asm volatile("" : "+v"(c.up));                                          // the weight loads stay inside the tile loop
         const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
         const int ntile = tile + tw_.step < limit ? tile + tw_.step : ntiles;      // ntiles = "none": zeros
 
-        all_chunks(c, [&](auto kc) {
+        all_chunks<STAMP, VAR>(c, [&](auto kc) {
             constexpr int K = decltype(kc)::value;
             // chunk K + 2 -> the d buffer chunk K was transformed from
             return [&, tile, ntile](int piece) {
                 if (K + 2 < NCH) dma_piece(tile, K + 2, K & 1, piece);
                 else dma_piece(ntile, K + 2 - NCH, K & 1, piece);
             };
-        }, std::make_integer_sequence<int, NCH>{});
+        }, t_wait, std::make_integer_sequence<int, NCH>{});
 
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // MFMA write -> VALU read distance
-        // epilogue: Y = A^T M A, bias, ReLU; a lane holds block (g2, tc) of channels 16 wv + 4 (lane >> 4) + i
+        unsigned long long te = 0;
+        if (STAMP) te = __builtin_amdgcn_s_memtime();
+        asm volatile("; W44_EPILOGUE_BEGIN\n\ts_nop 15\n\ts_nop 7" ::: "memory");      // MFMA write -> VALU read distance
+        // ... which only holds if no read of an accumulator is scheduled above it: to hipcc the MFMA results are ready where
+        // the asm statements stand, and it hoists the epilogue's v_accvgpr_reads right behind them.  Every accumulator is
+        // therefore re-defined here by an empty asm (ordered behind the wait states; no code).
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+            for (int xi = 0; xi < 36; xi += 4) {
+                if (in_agpr(g2, xi)) asm volatile("" : "+a"(c.acc[g2][xi]), "+a"(c.acc[g2][xi + 1]), "+a"(c.acc[g2][xi + 2]), "+a"(c.acc[g2][xi + 3]));
+                else asm volatile("" : "+v"(c.acc[g2][xi]), "+v"(c.acc[g2][xi + 1]), "+v"(c.acc[g2][xi + 2]), "+v"(c.acc[g2][xi + 3]));
+            }
+        // epilogue: Y = A^T M A, bias, ReLU; a lane holds block (g2, tc) of channels 16 wv + 4 (lane >> 4) + i.  Two
+        // channels at a time on the packed-f32 ALU (the halves of an accumulator quad are register pairs), one column /
+        // row per scheduling region so that at most a dozen accumulator copies are in flight; the bias enters through
+        // M[1][1], whose weight is 1 in all sixteen outputs.
         float* ob = out + ((size_t)b * C + 16 * wv + 4 * (lane >> 4)) * H * W + (size_t)ty0 * W + tx0 + 4 * tc;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float s[6][4];                                  // s[x][r]: A^T along y of column x
+            for (int pi = 0; pi < 2; ++pi) {
+                const f32x2 bias2 = {bv[2 * pi], bv[2 * pi + 1]};
+                f32x2 s[6][4];                                  // s[x][r]: A^T along y of column x
 #pragma unroll
-                for (int x = 0; x < 6; ++x)
-                    at6(c.acc[g2][x][i], c.acc[g2][6 + x][i], c.acc[g2][12 + x][i], c.acc[g2][18 + x][i], c.acc[g2][24 + x][i],
-                        c.acc[g2][30 + x][i], s[x]);
+                for (int x = 0; x < 6; ++x) {
+                    f32x2 m[6];
+#pragma unroll
+                    for (int y = 0; y < 6; ++y) {
+                        const f32x4 q = c.acc[g2][6 * y + x];
+                        m[y] = pi ? f32x2{q.z, q.w} : f32x2{q.x, q.y};
+                    }
+                    if (x == 1) m[1] += bias2;
+                    at6(m[0], m[1], m[2], m[3], m[4], m[5], s[x]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float y[4];
+                    f32x2 y[4];
                     at6(s[0][r], s[1][r], s[2][r], s[3][r], s[4][r], s[5][r], y);
-                    float4 v;
-                    v.x = y[0] + bv[i]; v.y = y[1] + bv[i]; v.z = y[2] + bv[i]; v.w = y[3] + bv[i];
-                    v.x = v.x > 0.f ? v.x : (LEAKY ? slope * v.x : 0.f);
-                    v.y = v.y > 0.f ? v.y : (LEAKY ? slope * v.y : 0.f);
-                    v.z = v.z > 0.f ? v.z : (LEAKY ? slope * v.z : 0.f);
-                    v.w = v.w > 0.f ? v.w : (LEAKY ? slope * v.w : 0.f);
-                    *reinterpret_cast<float4*>(ob + (size_t)i * H * W + (4 * g2 + r) * W) = v;
+                    float4 v0, v1;
+                    if (LEAKY) {
+                        v0.x = fmaxf(y[0].x, slope * y[0].x); v0.y = fmaxf(y[1].x, slope * y[1].x);
+                        v0.z = fmaxf(y[2].x, slope * y[2].x); v0.w = fmaxf(y[3].x, slope * y[3].x);
+                        v1.x = fmaxf(y[0].y, slope * y[0].y); v1.y = fmaxf(y[1].y, slope * y[1].y);
+                        v1.z = fmaxf(y[2].y, slope * y[2].y); v1.w = fmaxf(y[3].y, slope * y[3].y);
+                    } else {
+                        v0.x = fmaxf(y[0].x, 0.f); v0.y = fmaxf(y[1].x, 0.f); v0.z = fmaxf(y[2].x, 0.f); v0.w = fmaxf(y[3].x, 0.f);
+                        v1.x = fmaxf(y[0].y, 0.f); v1.y = fmaxf(y[1].y, 0.f); v1.z = fmaxf(y[2].y, 0.f); v1.w = fmaxf(y[3].y, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(ob + (size_t)(2 * pi) * H * W + (4 * g2 + r) * W) = v0;
+                    *reinterpret_cast<float4*>(ob + (size_t)(2 * pi + 1) * H * W + (4 * g2 + r) * W) = v1;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        asm volatile("; W44_EPILOGUE_END" ::: "memory");
+        if (STAMP) t_epi += __builtin_amdgcn_s_memtime() - te;
+    }
+    if (STAMP && tid == 0) {
+        stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+        stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+        stamps[4 * blockIdx.x + 2] = t_wait;
+        stamps[4 * blockIdx.x + 3] = t_epi;
     }
 }
 
@@ -349,10 +456,29 @@ int wino44_layer(const float* in, float* out, const float* upack_layer, const fl
                  int batch, int num_cu, float slope, hipStream_t s) {
     const int ntiles = batch * (H / w44::TR) * (W / w44::TC);
     const int grid = ntiles < num_cu ? ntiles : num_cu;
+    static const int var = getenv("PNP_W44_VAR") ? atoi(getenv("PNP_W44_VAR")) : 0;
     if (slope != 0.f)
         w44::k_mid_wino44<true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, slope);
+    else if (var == 5) w44::k_mid_wino44<false, false, 5><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
     else
         w44::k_mid_wino44<false><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+
+// diagnostic: `reps` back-to-back launches, the last one stamped; per workgroup {shader cycles, 100 MHz ticks, cycles in the
+// chunk-end waits + barriers, cycles in the epilogue} of the tile loop
+int wino44_debug_clock(const float* in, float* out, const float* upack_layer, const float* bias, int H, int W, int batch,
+                       int num_cu, int reps, unsigned long long* stamps_dev, hipStream_t s) {
+    const int ntiles = batch * (H / w44::TR) * (W / w44::TC);
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    for (int i = 0; i < reps - 1; ++i)
+        w44::k_mid_wino44<false><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
+    const int var = getenv("PNP_W44_VAR") ? atoi(getenv("PNP_W44_VAR")) : 0;     // ablation builds: timing only, wrong results
+#define PNP_W44_ABL(V) else if (var == V) w44::k_mid_wino44<false, true, V><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
+    if (var == 0) w44::k_mid_wino44<false, true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
+    PNP_W44_ABL(5) PNP_W44_ABL(10) PNP_W44_ABL(11) PNP_W44_ABL(12) PNP_W44_ABL(13) PNP_W44_ABL(14) PNP_W44_ABL(15)
+#undef PNP_W44_ABL
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }

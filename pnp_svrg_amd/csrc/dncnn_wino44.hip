@@ -41,7 +41,7 @@ constexpr int PPW = DBUF / 256 / 4;                   // 6 pieces per wave
 constexpr int VPL = 256;                              // floats per xi plane of V: [2 block rows][4 k-rows][16 blocks][2 k-steps]
 constexpr int VBUF = 36 * VPL;
 constexpr int LDS_FLOATS = 2 * DBUF + 2 * VBUF;       // 30720 floats = 120 KiB
-constexpr int URING = 8;                              // weight loads in flight per lane
+constexpr int URING = 12;                              // weight loads in flight per lane
 constexpr unsigned DUMMY = 1u << 27;                  // descriptor flag: padding chunk of a plane
 
 // B^T of F(4,3) applied to six values
@@ -191,7 +191,7 @@ template <int K, int P, int VAR, typename DMA> __device__ __forceinline__ void s
             mfma_j0<K, X1, 1>(c, u.z, b1.x);
             mfma<in_agpr(0, X1)>(c.acc[0][X1], u.w, b0.y);
             mfma<in_agpr(1, X1)>(c.acc[1][X1], u.w, b1.y);
-            c.ur[SQ % URING] = c.up[((SQ + URING) % (NCH * 18)) * 64];
+            if constexpr (SQ + URING < NCH * 18) c.ur[SQ % URING] = c.up[(SQ + URING) * 64];
             PNP_SLOT();
         }
         return;
@@ -222,7 +222,7 @@ template <int K, int P, int VAR, typename DMA> __device__ __forceinline__ void s
     PNP_SLOT();
     mfma<in_agpr(1, X1)>(c.acc[1][X1], u.w, c1.y);   PNP_SLOT();          // M8
     if constexpr (VAR != 14 && VAR != 15) slice_lds<DPAR, P, 2>(c);
-    if constexpr (VAR != 12 && VAR != 15) c.ur[SQ % URING] = c.up[((SQ + URING) % (NCH * 18)) * 64];
+    if constexpr (VAR != 12 && VAR != 15 && SQ + URING < NCH * 18) c.ur[SQ % URING] = c.up[(SQ + URING) * 64];
     PNP_SLOT();
 }
 template <int K, int VAR, typename DMA, int... P> __device__ __forceinline__ void chunk_steps(Ctx& c, DMA&& dma, std::integer_sequence<int, P...>) {
@@ -238,8 +238,8 @@ template <int K, bool STAMP, int VAR, typename DMA> __device__ __forceinline__ v
     chunk_steps<K, VAR>(c, dma, std::make_integer_sequence<int, 18>{});
     unsigned long long ta = 0;
     if (STAMP) ta = __builtin_amdgcn_s_memtime();
-    // this chunk's DMA pieces (issued in steps 0 .. PPW - 1, before more than URING weight loads) have landed
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(URING) : "memory");
+    // this chunk's DMA pieces have landed: they were issued in steps 0 .. PPW - 1, each before its step's weight load
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(18 - PPW) : "memory");
     __syncthreads();
     if (STAMP) t_wait += __builtin_amdgcn_s_memtime() - ta;
 }
@@ -296,17 +296,31 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
         pdesc[i] = r < PR * 18 ? ((unsigned)((c * H + ry) * W + cx4) | (edge << 28)) : DUMMY;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
-    // piece i of chunk k of tile t -> d buffer `buf`; t == ntiles: zeros
-    auto dma_piece = [&](int t, int k, int buf, int i) {
+    // DMA state of a tile t (t == ntiles: "none", every lane reads zeros): the buffer base of its chunk 0 and, per piece, the
+    // lane's byte offset (or an offset beyond num_records) -- the same for all chunks of the tile, whose bases are
+    // chunk_bytes apart
+    struct TileDma { size_t base; unsigned voff[PPW]; };
+    const size_t chunk_bytes = (size_t)KC * H * W * 4;
+    auto tile_dma = [&](int t) {
+        TileDma td;
         const int b = t / tiles_per_img, t2 = t - b * tiles_per_img;
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
-        const size_t base = (size_t)in + 4 * ((((size_t)b * C + k * KC) * H + ty0 - 1) * (size_t)W + tx0 - 4);
-        i32x4 rs;
-        rs.x = (int)(unsigned)base; rs.y = (int)(unsigned)(base >> 32) & 0xFFFF; rs.z = (int)0x80000000u; rs.w = 0x00020000;
+        td.base = (size_t)in + 4 * ((((size_t)b * C) * H + ty0 - 1) * (size_t)W + tx0 - 4);
         const unsigned bad = t < ntiles ? ((((ty0 == 0 ? 1u : 0u) | (ty0 + TR == H ? 2u : 0u) | (tx0 == 0 ? 4u : 0u) | (tx0 + TC == W ? 8u : 0u)) << 28) | DUMMY)
                                         : 0xFFFFFFFFu;
-        const unsigned voff = (pdesc[i] & bad) == 0u ? 4u * (pdesc[i] & 0x07FFFFFFu) : 0x80000000u;
-        dma_piece_asm(voff, rs, lds0 + 4u * (unsigned)(buf * DBUF + (wv + 4 * i) * 256));
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) td.voff[i] = (pdesc[i] & bad) == 0u ? 4u * (pdesc[i] & 0x07FFFFFFu) : 0x80000000u;
+        return td;
+    };
+    auto chunk_rsrc = [&](const TileDma& td, int k) {
+        const size_t base = td.base + (size_t)k * chunk_bytes;
+        i32x4 rs;
+        rs.x = (int)(unsigned)base; rs.y = (int)(unsigned)(base >> 32) & 0xFFFF; rs.z = (int)0x80000000u; rs.w = 0x00020000;
+        return rs;
+    };
+    // piece i of a chunk -> d buffer `buf`
+    auto dma_piece = [&](const TileDma& td, i32x4 rs, int buf, int i) {
+        dma_piece_asm(td.voff[i], rs, lds0 + 4u * (unsigned)(buf * DBUF + (wv + 4 * i) * 256));
     };
 
     float* const dbuf = lds;
@@ -326,11 +340,11 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
     int tile = tw_.first;
     const int limit = tw_.limit < ntiles ? tw_.limit : ntiles;
     {
-        const int t0 = tile < limit ? tile : ntiles;
+        const TileDma td0 = tile_dma(tile < limit ? tile : ntiles);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_piece(t0, 0, 0, i);
+        for (int i = 0; i < PPW; ++i) dma_piece(td0, chunk_rsrc(td0, 0), 0, i);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_piece(t0, 1, 1, i);
+        for (int i = 0; i < PPW; ++i) dma_piece(td0, chunk_rsrc(td0, 1), 1, i);
 #pragma unroll
         for (int i = 0; i < URING; ++i) c.ur[i] = c.up[i * 64];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -347,13 +361,13 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
         const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
         const int ntile = tile + tw_.step < limit ? tile + tw_.step : ntiles;      // ntiles = "none": zeros
 
+        const TileDma cur = tile_dma(tile), nxt = tile_dma(ntile);
         all_chunks<STAMP, VAR>(c, [&](auto kc) {
             constexpr int K = decltype(kc)::value;
-            // chunk K + 2 -> the d buffer chunk K was transformed from
-            return [&, tile, ntile](int piece) {
-                if (K + 2 < NCH) dma_piece(tile, K + 2, K & 1, piece);
-                else dma_piece(ntile, K + 2 - NCH, K & 1, piece);
-            };
+            // chunk K + 2 (of this tile, or chunk 0 / 1 of the next) -> the d buffer chunk K was transformed from
+            const TileDma& td = K + 2 < NCH ? cur : nxt;
+            const i32x4 rs = chunk_rsrc(td, (K + 2) % NCH);
+            return [&, rs](int piece) { dma_piece(td, rs, K & 1, piece); };
         }, t_wait, std::make_integer_sequence<int, NCH>{});
 
         unsigned long long te = 0;
@@ -375,9 +389,16 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
         // M[1][1], whose weight is 1 in all sixteen outputs.
         float* ob = out + ((size_t)b * C + 16 * wv + 4 * (lane >> 4)) * H * W + (size_t)ty0 * W + tx0 + 4 * tc;
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
+        for (int blk = 0; blk < 4; ++blk) {
+            {
+                const int g2 = 1 - (blk >> 1), pi = blk & 1;        // block row 1 first: it frees the eight VGPR accumulator quads
+                // no weight load is in flight across the epilogue (a spilled in-flight load costs its whole latency); the
+                // ring's first entries of the next tile go out before the last block
+                if (blk == 3) {
 #pragma unroll
-            for (int pi = 0; pi < 2; ++pi) {
+                    for (int i = 0; i < URING; ++i) c.ur[i] = c.up[i * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const f32x2 bias2 = {bv[2 * pi], bv[2 * pi + 1]};
                 f32x2 s[6][4];                                  // s[x][r]: A^T along y of column x
 #pragma unroll

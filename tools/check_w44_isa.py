@@ -30,7 +30,7 @@ def check(asm_text):
     blocks = re.split(r'\n(?=_ZN3pnp3w4412k_mid_wino44[^\n]*:\s)', asm_text)
     for blk in blocks[1:]:
         name = blk.split(':', 1)[0]
-        if not re.search(r'Li[05]EEEv', name):                     # ablation builds (timing only) are not checked
+        if not re.search(r'ILb[01]ELb0ELi[05]EEEv', name):         # stamped / ablation builds (timing only) are not checked
             continue
         lines = blk.split('\n')
         end = next((i for i, l in enumerate(lines) if l.startswith('.Lfunc_end')), len(lines))

@@ -710,10 +710,10 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
                     upk[(((size_t)l * 4 + wv) * WINO_U + s) * 64 + lane] = (float)u;
                 }
     {
-        // conv kernel of the middle layers: 4 = Winograd F(4,3) (default where the image size allows it), 1 = F(2,3),
-        // 0 = direct, 3 = opt-in split-fp16
+        // conv kernel of the middle layers: 5 = Winograd F(4x4,3x3) (default where the image size allows it), 4 = F(4,3)
+        // along x, 1 = F(2,3) along x, 0 = direct, 3 = opt-in split-fp16
         const char* ev = getenv("PNP_DNCNN_WINOGRAD");
-        p->use_wino = ev ? atoi(ev) : 4;
+        p->use_wino = ev ? atoi(ev) : 5;
         if (p->use_wino == 5 && !wino44_supports(H, W)) p->use_wino = 4;
         if (p->use_wino == 4 && !wino4_supports(H, W)) p->use_wino = 1;
     }

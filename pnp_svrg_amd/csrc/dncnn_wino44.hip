@@ -477,10 +477,8 @@ int wino44_layer(const float* in, float* out, const float* upack_layer, const fl
                  int batch, int num_cu, float slope, hipStream_t s) {
     const int ntiles = batch * (H / w44::TR) * (W / w44::TC);
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    static const int var = getenv("PNP_W44_VAR") ? atoi(getenv("PNP_W44_VAR")) : 0;
     if (slope != 0.f)
         w44::k_mid_wino44<true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, slope);
-    else if (var == 5) w44::k_mid_wino44<false, false, 5><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
     else
         w44::k_mid_wino44<false><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
     PNP_CHECK_LAUNCH();
@@ -495,11 +493,15 @@ int wino44_debug_clock(const float* in, float* out, const float* upack_layer, co
     const int grid = ntiles < num_cu ? ntiles : num_cu;
     for (int i = 0; i < reps - 1; ++i)
         w44::k_mid_wino44<false><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
-    const int var = getenv("PNP_W44_VAR") ? atoi(getenv("PNP_W44_VAR")) : 0;     // ablation builds: timing only, wrong results
-#define PNP_W44_ABL(V) else if (var == V) w44::k_mid_wino44<false, true, V><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
+    const int var = getenv("PNP_W44_VAR") ? atoi(getenv("PNP_W44_VAR")) : 0;
     if (var == 0) w44::k_mid_wino44<false, true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
+#ifdef PNP_W44_ABLATIONS   // timing-only builds (wrong results): 5 = everything in front of each xi's MFMAs, 10 = no transform
+                           // arithmetic, 11 = no DMA, 12 = no weight reloads, 13 = no B reads, 14 = no transform LDS traffic, 15 = bare MFMAs
+#define PNP_W44_ABL(V) else if (var == V) w44::k_mid_wino44<false, true, V><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
     PNP_W44_ABL(5) PNP_W44_ABL(10) PNP_W44_ABL(11) PNP_W44_ABL(12) PNP_W44_ABL(13) PNP_W44_ABL(14) PNP_W44_ABL(15)
 #undef PNP_W44_ABL
+#endif
+    else PNP_CHECK_ARG(false, "PNP_W44_VAR: this library was built without -DPNP_W44_ABLATIONS");
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }

@@ -238,3 +238,17 @@ def test_grid_search_reduction_and_csv(tmp_path):
     assert lines[0] == 'Results:' and len(lines) == 5
     assert lines[1].split(',')[:5] == ['csmri', 'TV', 'pnp_svrg', '0.2', '20.0']
     assert lines[1].split(',')[6:] == ['PARAMETERS:', 'eta', '2.0', 'T2', '5']
+
+
+def test_w44_accumulators_untouched():
+    """The MFMAs of the F(4x4,3x3) conv kernel are inline asm, so hipcc's hazard recognizer does not protect their
+    results: a compiler-inserted copy or early read of an accumulator next to them would be stale in the registers the
+    MFMA's last pass writes.  tools/check_w44_isa.py compiles csrc/dncnn_wino44.hip to assembly and verifies, for every
+    production instantiation, that each of the 72 accumulator quads stays in its registers (16 MFMAs each) and that no
+    other instruction touches an accumulator AGPR outside the epilogue, which starts with the wait states."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_w44_isa.py')], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert '0 problem(s)' in out.stdout

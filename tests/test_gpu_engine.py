@@ -145,8 +145,8 @@ def test_bench_line_smoke():
     rf = line['roofline']
     assert rf['bound'] == 'mfma' and 0 < rf['frac'] < 1
     # frac is EXECUTED matrix-core work over the peak; the algorithmic rate is reported beside it
-    assert rf['winograd_reduction'] == 2.0                       # F(4,3) is the default conv kernel at W % 64 == 0
-    assert abs(rf['algorithmic_tflops'] / rf['achieved'] - 2.0) < 0.01
+    assert rf['winograd_reduction'] == 4.0                       # F(4x4,3x3) is the default conv kernel at H % 8 == 0, W % 64 == 0
+    assert abs(rf['algorithmic_tflops'] / rf['achieved'] - 4.0) < 0.01
     assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
 
 

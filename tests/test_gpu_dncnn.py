@@ -104,6 +104,27 @@ def test_winograd_vs_direct(W15, io):
             assert np.abs(rb[B - 1] - io['net256_out']).max() <= 2e-5
 
 
+def test_wino44_shapes_and_edges():
+    """The F(4x4,3x3) kernel on non-square images whose 8 x 64 regions all touch an edge, batches whose region count does
+    not divide the grid (plain tile walk) and single-region images: equal to the direct kernel to fp32 rounding; constant
+    offset far from zero (every halo value matters); a width outside its grid falls back to F(2,3)."""
+    from pnp_svrg_amd import ops
+    from pnp_svrg_amd.denoisers import random_dncnn_weights
+    w = random_dncnn_weights(5, seed=3)
+    rng = np.random.default_rng(8)
+    for (H, Wd, B) in ((8, 64, 1), (72, 128, 3), (128, 64, 5), (64, 192, 2)):
+        x = rng.random((B, H, Wd)).astype(np.float32) + 3.0
+        r0 = ops.DncnnPlan(w, H, Wd, B, winograd=0).forward(dev(x)).cpu().numpy()
+        r5 = ops.DncnnPlan(w, H, Wd, B, winograd=5).forward(dev(x)).cpu().numpy()
+        assert np.abs(r5 - r0).max() <= 2e-5 * max(1.0, np.abs(r0).max()), (H, Wd, B, np.abs(r5 - r0).max())
+    x96 = rng.random((1, 40, 96)).astype(np.float32)                    # W % 64 != 0: the default is F(2,3) there
+    rd = ops.DncnnPlan(w, 40, 96, 1).forward(dev(x96)).cpu().numpy()
+    assert np.array_equal(rd, ops.DncnnPlan(w, 40, 96, 1, winograd=1).forward(dev(x96)).cpu().numpy())
+    with pytest.raises(Exception):
+        ops.DncnnPlan(w, 40, 96, 1, winograd=5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name', ['SimpleCNN', 'RealSN_SimpleCNN'])
 def test_simplecnn_family(name):
     """the 4-layer SimpleCNN / RealSN_SimpleCNN denoisers run through the same plan (n_mid = 2,

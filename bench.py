@@ -227,7 +227,7 @@ class Workload:
         fl = NLM_FLOP_PER_PIXEL * H * W * B
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         return {'bound': 'valu',
-                'kernel': 'pnp::k_nlm<float,5> (11x11 search window x 5x5 patches from an LDS-staged tile, f32; nominal FLOPs before '
+                'kernel': 'pnp::k_nlm_strip<float,5,5> (11x11 search window x 5x5 patches, neighbour patches in a register strip fed from an LDS-staged tile, f32; nominal FLOPs before '
                           'the reference\'s early exits and border clipping)',
                 'achieved': round(ach, 2), 'peak': F32_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F32_VALU_PEAK_TFLOPS, 4),
                 'traffic': None, 'launch_ms': round(ms, 4), 'flops_per_launch': fl,

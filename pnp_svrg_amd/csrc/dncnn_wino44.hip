@@ -105,8 +105,8 @@ __device__ __forceinline__ void dma_piece_asm(unsigned voff, i32x4 rsrc, unsigne
 
 struct Patch {
     f32x2 a; f32x4 m; f32x2 e;                                 // one patch row in flight: LDS columns 4tc + 2..3, 4..7, 8..9
-    float t[6][6];
-    float v[6];                                                // one transformed column on its way to the V image
+    f32x2 t[6][3];                                             // row transforms as register pairs: (V0, V5), (V1, V2), (V3, V4) of row r
+    f32x2 v[6];                                                // one transformed pair of columns on its way to the V image
 };
 struct Ctx {
     f32x4 acc[2][36];
@@ -133,26 +133,64 @@ template <int DPAR, int R, int HALF> __device__ __forceinline__ void patch_load(
     if (HALF == 0) { c.P.a = *(const lds_f2*)(row + 2); c.P.e = *(const lds_f2*)(row + 8); }
     else c.P.m = *(const lds_f4*)(row + 4);
 }
-// transform slice SL of the patch (d buffer DPAR -> V buffer DPAR): 0..5 = row transforms, 6..11 = column transforms;
-// the six V values of column SL - 6 wait in P.v for their write slots
+// The transform on the packed-f32 ALU (a v_pk_* beside f32 MFMAs costs what one plain instruction does).  Row pass of
+// B^T d B: the loaded row holds (d1, d2) and (d3, d4) as aligned register pairs, so
+//     (t2, t1) = (d3, d4) - 4 (d1, d2)      (sd, t3) = (d3, d4) - (d1, d2)
+//     (V1, V2) = (t1 + t2, t1 - t2)         (V3, V4) = (t3 + 2 sd, t3 - 2 sd)        [half-selects: op_sel, hand-written]
+// and V0, V5 (their inputs straddle the pairs) stay scalar: 8 instructions instead of 12.  The results are kept as the
+// pairs (V0, V5), (V1, V2), (V3, V4), so the column pass runs on whole pairs: 12 packed instructions for two columns.
+__device__ __forceinline__ f32x2 pk_sum_diff(f32x2 a) {             // (a.lo + a.hi, a.hi - a.lo)
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_hi_pm_2lo(f32x2 a) {            // (a.hi + 2 a.lo, a.hi - 2 a.lo)
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+// B^T of F(4,3) on six pairs
+__device__ __forceinline__ void bt6_pk(f32x2 q0, f32x2 q1, f32x2 q2, f32x2 q3, f32x2 q4, f32x2 q5, f32x2 (&v)[6]) {
+    const f32x2 t1 = q4 - 4.f * q2, t2 = q3 - 4.f * q1;
+    const f32x2 t3 = q4 - q2, sd = q3 - q1;
+    v[0] = 4.f * q0 + (q4 - 5.f * q2);
+    v[1] = t1 + t2;
+    v[2] = t1 - t2;
+    v[3] = 2.f * sd + t3;
+    v[4] = t3 - 2.f * sd;
+    v[5] = 4.f * q1 + (q5 - 5.f * q3);
+}
+// transform slice SL of the patch (d buffer DPAR -> V buffer DPAR): 0..5 = row transforms, 6 / 8 / 10 = column transforms of
+// the column pairs (0, 5) / (1, 2) / (3, 4); the six value pairs wait in P.v for their write slots
+constexpr int col_pair(int sl) { return (sl - 6) / 2; }
+constexpr bool is_col_slice(int sl) { return sl == 6 || sl == 8 || sl == 10; }
 template <int SL> __device__ __forceinline__ void slice_valu(Ctx& c) {
     Patch& P = c.P;
     if constexpr (SL < 6) {
         asm volatile("" :: "v"(P.a.x), "v"(P.e.y));
-        bt6(P.a.y, P.m.x, P.m.y, P.m.z, P.m.w, P.e.x, P.t[SL]);
-    } else if constexpr (SL < 12) {
-        constexpr int x = SL - 6;
-        bt6(P.t[0][x], P.t[1][x], P.t[2][x], P.t[3][x], P.t[4][x], P.t[5][x], P.v);
+        const f32x2 p12 = {P.m.x, P.m.y}, p34 = {P.m.z, P.m.w};
+        const f32x2 A = p34 - 4.f * p12;                          // (t2, t1)
+        const f32x2 Bv = p34 - p12;                               // (sd, t3)
+        P.t[SL][1] = pk_sum_diff(A);
+        P.t[SL][2] = pk_hi_pm_2lo(Bv);
+        P.t[SL][0].x = __builtin_fmaf(4.f, P.a.y, __builtin_fmaf(-5.f, P.m.y, P.m.w));
+        P.t[SL][0].y = __builtin_fmaf(4.f, P.m.x, __builtin_fmaf(-5.f, P.m.z, P.e.x));
+    } else if constexpr (is_col_slice(SL)) {
+        constexpr int cp = col_pair(SL);
+        bt6_pk(P.t[0][cp], P.t[1][cp], P.t[2][cp], P.t[3][cp], P.t[4][cp], P.t[5][cp], P.v);
     }
 }
-// LDS operation N (0..2) of slice SL: the next patch row's reads (SL < 5) or two of the six V writes (6 <= SL < 12)
+// LDS operation N (0..2) of slice SL: the next patch row's reads (SL < 5) or two of the six pairs of V writes (column slices)
 template <int DPAR, int SL, int N> __device__ __forceinline__ void slice_lds(Ctx& c) {
     if constexpr (SL < 5) {
         if constexpr (N < 2) patch_load<DPAR, SL + 1, N>(c);
-    } else if constexpr (SL >= 6 && SL < 12) {
-        constexpr int x = SL - 6;
-        c.vdst[DPAR][((2 * N) * 6 + x) * VPL] = c.P.v[2 * N];
-        c.vdst[DPAR][((2 * N + 1) * 6 + x) * VPL] = c.P.v[2 * N + 1];
+    } else if constexpr (is_col_slice(SL)) {
+        constexpr int cp = col_pair(SL), xa = cp == 0 ? 0 : cp == 1 ? 1 : 3, xb = cp == 0 ? 5 : cp == 1 ? 2 : 4;
+#pragma unroll
+        for (int y = 2 * N; y < 2 * N + 2; ++y) {
+            c.vdst[DPAR][(y * 6 + xa) * VPL] = c.P.v[y].x;
+            c.vdst[DPAR][(y * 6 + xb) * VPL] = c.P.v[y].y;
+        }
     }
 }
 template <int VPAR, int XI, int G> __device__ __forceinline__ void b_load(Ctx& c) {

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpnp_hip.so')
+LIB_PATH = os.environ.get('PNP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libpnp_hip.so')   # PNP_HIP_LIB: A/B timing of kernel builds
 
 F32, F64 = 0, 1
 

@@ -41,7 +41,7 @@ constexpr int PPW = DBUF / 256 / 4;                   // 6 pieces per wave
 constexpr int VPL = 256;                              // floats per xi plane of V: [2 block rows][4 k-rows][16 blocks][2 k-steps]
 constexpr int VBUF = 36 * VPL;
 constexpr int LDS_FLOATS = 2 * DBUF + 2 * VBUF;       // 30720 floats = 120 KiB
-constexpr int URING = 12;                              // weight loads in flight per lane
+constexpr int URING = 18;                              // weight loads in flight per lane
 constexpr unsigned DUMMY = 1u << 27;                  // descriptor flag: padding chunk of a plane
 
 // B^T of F(4,3) applied to six values

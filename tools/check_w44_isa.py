@@ -23,7 +23,7 @@ def regs(text):
 
 
 def check(asm_text):
-    """Per kernel instantiation: (a) exactly 72 accumulator quads, each the destination of exactly 16 MFMAs (an accumulator
+    """Per kernel instantiation (also (c): m0 is used by the LDS-DMA statements only): (a) exactly 72 accumulator quads, each the destination of exactly 16 MFMAs (an accumulator
     that was moved shows up as extra quads with fewer); (b) outside the epilogue no instruction other than an MFMA names an
     accumulator AGPR (all 256 are accumulators; the 8 VGPR quads are legitimately reused between tiles, (a) covers them)."""
     problems, kernels = [], 0
@@ -61,6 +61,12 @@ def check(asm_text):
                 problems.append(f'{name}: line {i}: `{code.strip()}` touches accumulator register(s) {sorted(hit)[:4]}')
         if n_epi == 0:
             problems.append(f'{name}: no epilogue marker found')
+        # (c) M0 belongs to the hand-written LDS-DMA statements (it is not on their clobber list: hipcc reserves it):
+        # every mention of m0 must be one of their `s_mov_b32 m0, ...`, one per DMA instruction
+        m0 = [l for l in lines if re.search(r'\bm0\b', l.split(';')[0])]
+        dma = [l for l in lines if 'buffer_load_dwordx4' in l and ' lds' in l]
+        if len(m0) != len(dma) or any('s_mov_b32 m0' not in l for l in m0):
+            problems.append(f'{name}: {len(m0)} uses of m0 for {len(dma)} LDS-DMA instructions (the compiler touches m0?)')
     return kernels, problems
 
 

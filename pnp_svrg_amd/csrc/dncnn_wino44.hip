@@ -30,17 +30,24 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int C = 64;
-constexpr int TR = 8, TC = 64;                        // output region: 2 x 16 blocks of 4 x 4
-constexpr int PR = TR + 2;                            // halo rows
+constexpr int TC = 64;                                // region width: 16 blocks of 4 x 4
 constexpr int PC = 72;                                // LDS row: image columns [tx0 - 4, tx0 + 68) = eighteen 16-byte chunks
-constexpr int PLANE = 768;                            // 720 payload + 48 pad: 0 mod 64 dwords (ds_read_b128 lane groups mix two planes)
 constexpr int KC = 8;                                 // input channels per chunk
 constexpr int NCH = C / KC;
-constexpr int DBUF = KC * PLANE;                      // 6144 floats = 24 DMA pieces of 1 KiB
-constexpr int PPW = DBUF / 256 / 4;                   // 6 pieces per wave
-constexpr int VPL = 256;                              // floats per xi plane of V: [2 block rows][4 k-rows][16 blocks][2 k-steps]
-constexpr int VBUF = 36 * VPL;
-constexpr int LDS_FLOATS = 2 * DBUF + 2 * VBUF;       // 30720 floats = 120 KiB
+// NG = block rows per region: 2 (8 x 64 outputs, 72 accumulator quads per wave; the throughput form) or 1 (4 x 64, 36 quads:
+// twice the regions for launches that would otherwise leave CUs idle -- a single 256 x 256 image is 128 regions of 8 x 64)
+template <int NG_> struct Geo {
+    static constexpr int NG = NG_;
+    static constexpr int TR = 4 * NG, PR = TR + 2;                 // output rows, halo rows
+    static constexpr int PLANE = NG == 2 ? 768 : 512;              // PR x 72 payload + pad: 0 mod 64 dwords (ds_read_b128 lane groups mix two planes)
+    static constexpr int DBUF = KC * PLANE;                        // 24 / 16 DMA pieces of 1 KiB
+    static constexpr int PPW = DBUF / 256 / 4;                     // 6 / 4 pieces per wave
+    static constexpr int VPL = 128 * NG;                           // floats per xi plane of V: [NG block rows][4 k-rows][16 blocks][2 k-steps]
+    static constexpr int VBUF = 36 * VPL;
+    static constexpr int LDS_FLOATS = 2 * DBUF + 2 * VBUF;         // 120 KiB / 68 KiB
+    static constexpr int NQ_AGPR = NG == 2 ? 64 : 36;              // accumulator quads kept in AGPRs (of 72: block row 0 and xi < 28 of row 1; of 36: all)
+    static constexpr bool in_agpr(int g, int xi) { return g * 36 + xi < NQ_AGPR; }
+};
 constexpr int URING = 18;                              // weight loads in flight per lane
 constexpr unsigned DUMMY = 1u << 27;                  // descriptor flag: padding chunk of a plane
 
@@ -81,8 +88,6 @@ template <bool AG> __device__ __forceinline__ void mfma_first(f32x4& acc, float 
     if (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" PNP_MFMA_POST : "=&a"(acc) : "v"(w), "v"(v));
     else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" PNP_MFMA_POST : "=&v"(acc) : "v"(w), "v"(v));
 }
-constexpr int NQ_AGPR = 64;                                  // accumulator quads (of 72) kept in AGPRs: block row 0, and xi < 28 of row 1
-__host__ __device__ constexpr bool in_agpr(int g, int xi) { return g * 36 + xi < NQ_AGPR; }
 
 // ---- memory streams of the main loop ------------------------------------------------------------------------------------------
 // * LDS-DMA (activations): inline asm, invisible to the compiler's s_waitcnt insertion -- visible, it makes every LDS read
@@ -108,11 +113,13 @@ struct Patch {
     f32x2 t[6][3];                                             // row transforms as register pairs: (V0, V5), (V1, V2), (V3, V4) of row r
     f32x2 v[6];                                                // one transformed pair of columns on its way to the V image
 };
-struct Ctx {
-    f32x4 acc[2][36];
+template <int NG_> struct Ctx {
+    static constexpr int NG = NG_;
+    using G = Geo<NG_>;
+    f32x4 acc[NG_][36];
     f32x4 ur[URING];
     Patch P;
-    f32x2 b[2][2];                                             // B operands of the current / next xi: [parity][block row]
+    f32x2 b[2][NG_];                                           // B operands of the current / next xi: [parity][block row]
     const lds_f* dsrc[2];                                      // this lane's patch in the two d buffers
     lds_f* vdst[2];                                            // its V item in the two V buffers
     const lds_f* vsrc0[2];                                     // its B operands (block row 0 / 1) in the two V buffers;
@@ -128,7 +135,7 @@ struct Ctx {
 // patch row R of d buffer DPAR, in two halves; all ten floats are "used" (patch_rows) so that the reads stay one
 // conflict-free ds_read_b128 and two ds_read_b64 (narrowed to the six needed values they become three 4-way
 // bank-conflicting ds_read2_b32)
-template <int DPAR, int R, int HALF> __device__ __forceinline__ void patch_load(Ctx& c) {
+template <int DPAR, int R, int HALF, typename CT> __device__ __forceinline__ void patch_load(CT& c) {
     const lds_f* row = c.dsrc[DPAR] + R * PC;                    // 16-byte aligned
     if (HALF == 0) { c.P.a = *(const lds_f2*)(row + 2); c.P.e = *(const lds_f2*)(row + 8); }
     else c.P.m = *(const lds_f4*)(row + 4);
@@ -164,7 +171,7 @@ __device__ __forceinline__ void bt6_pk(f32x2 q0, f32x2 q1, f32x2 q2, f32x2 q3, f
 // the column pairs (0, 5) / (1, 2) / (3, 4); the six value pairs wait in P.v for their write slots
 constexpr int col_pair(int sl) { return (sl - 6) / 2; }
 constexpr bool is_col_slice(int sl) { return sl == 6 || sl == 8 || sl == 10; }
-template <int SL> __device__ __forceinline__ void slice_valu(Ctx& c) {
+template <int SL, typename CT> __device__ __forceinline__ void slice_valu(CT& c) {
     Patch& P = c.P;
     if constexpr (SL < 6) {
         asm volatile("" :: "v"(P.a.x), "v"(P.e.y));
@@ -181,7 +188,8 @@ template <int SL> __device__ __forceinline__ void slice_valu(Ctx& c) {
     }
 }
 // LDS operation N (0..2) of slice SL: the next patch row's reads (SL < 5) or two of the six pairs of V writes (column slices)
-template <int DPAR, int SL, int N> __device__ __forceinline__ void slice_lds(Ctx& c) {
+template <int DPAR, int SL, int N, typename CT> __device__ __forceinline__ void slice_lds(CT& c) {
+    constexpr int VPL = CT::G::VPL;
     if constexpr (SL < 5) {
         if constexpr (N < 2) patch_load<DPAR, SL + 1, N>(c);
     } else if constexpr (is_col_slice(SL)) {
@@ -193,81 +201,75 @@ template <int DPAR, int SL, int N> __device__ __forceinline__ void slice_lds(Ctx
         }
     }
 }
-template <int VPAR, int XI, int G> __device__ __forceinline__ void b_load(Ctx& c) {
-    if (G == 0) c.b[XI & 1][0] = *(const lds_f2*)(c.vsrc0[VPAR] + XI * VPL);
-    else c.b[XI & 1][1] = *(const lds_f2*)(c.vsrc1[VPAR] + XI * VPL);
+template <int VPAR, int XI, int GR, typename CT> __device__ __forceinline__ void b_load(CT& c) {
+    if constexpr (GR < CT::NG) {
+        if (GR == 0) c.b[XI & 1][0] = *(const lds_f2*)(c.vsrc0[VPAR] + XI * CT::G::VPL);
+        else c.b[XI & 1][GR] = *(const lds_f2*)(c.vsrc1[VPAR] + XI * CT::G::VPL);
+    }
 }
-template <int K, int XI, int G> __device__ __forceinline__ void mfma_j0(Ctx& c, float u, float b) {
-    if constexpr (K == 0) mfma_first<in_agpr(G, XI)>(c.acc[G][XI], u, b);
-    else mfma<in_agpr(G, XI)>(c.acc[G][XI], u, b);
+// MFMA of block row GR (nothing for a block row the region does not have): first k-step of a xi (constant-zero SrcC in
+// chunk 0) / second k-step
+template <int K, int XI, int GR, typename CT> __device__ __forceinline__ void mfma_j0(CT& c, float u, f32x2 (&b)[CT::NG]) {
+    if constexpr (GR < CT::NG) {
+        if constexpr (K == 0) mfma_first<CT::G::in_agpr(GR, XI)>(c.acc[GR][XI], u, b[GR].x);
+        else mfma<CT::G::in_agpr(GR, XI)>(c.acc[GR][XI], u, b[GR].x);
+    }
+}
+template <int XI, int GR, typename CT> __device__ __forceinline__ void mfma_j1(CT& c, float u, f32x2 (&b)[CT::NG]) {
+    if constexpr (GR < CT::NG) mfma<CT::G::in_agpr(GR, XI)>(c.acc[GR][XI], u, b[GR].y);
 }
 
-// step (K, P) of the main loop: xi = 2P, 2P + 1; dma(piece) issues DMA piece `piece` of chunk K + 2
-// VAR (diagnostic): 5 = the order of the first, compiler-scheduled version (everything in front of each xi's four MFMAs)
-template <int K, int P, int VAR, typename DMA> __device__ __forceinline__ void step(Ctx& c, DMA&& dma) {
+// step (K, P) of the main loop: xi = 2P, 2P + 1; dma(piece) issues DMA piece `piece` of chunk K + 2.  With one block row
+// (NG = 1) the slots of M2, M4, M6, M8 and of their B reads are empty.
+// VAR (ablation builds, timing only): 10 = no transform arithmetic, 11 = no DMA, 12 = no weight reloads, 13 = no B reads,
+// 14 = no transform LDS traffic, 15 = bare MFMAs
+template <int K, int P, int VAR, typename CT, typename DMA> __device__ __forceinline__ void step(CT& c, DMA&& dma) {
     constexpr int X0 = 2 * P, X1 = 2 * P + 1, SQ = K * 18 + P;
-    constexpr int VPAR = K & 1, DPAR = (K + 1) & 1;
+    constexpr int VPAR = K & 1, DPAR = (K + 1) & 1, NG = CT::NG;
     const f32x4 u = c.ur[SQ % URING];
-    if constexpr (VAR == 5) {
-        {
-            const f32x2 b0 = c.b[0][0], b1 = c.b[0][1];
-            b_load<VPAR, X1, 0>(c); b_load<VPAR, X1, 1>(c);
-            slice_valu<P>(c); slice_lds<DPAR, P, 0>(c); slice_lds<DPAR, P, 1>(c); slice_lds<DPAR, P, 2>(c);
-            asm volatile("s_nop 1" ::: "memory");
-            mfma_j0<K, X0, 0>(c, u.x, b0.x);
-            mfma_j0<K, X0, 1>(c, u.x, b1.x);
-            mfma<in_agpr(0, X0)>(c.acc[0][X0], u.y, b0.y);
-            mfma<in_agpr(1, X0)>(c.acc[1][X0], u.y, b1.y);
-            PNP_SLOT();
-        }
-        {
-            const f32x2 b0 = c.b[1][0], b1 = c.b[1][1];
-            if constexpr (X1 + 1 < 36) { b_load<VPAR, X1 + 1, 0>(c); b_load<VPAR, X1 + 1, 1>(c); }
-            if constexpr (P < PPW) dma(P);
-            asm volatile("s_nop 1" ::: "memory");
-            mfma_j0<K, X1, 0>(c, u.z, b0.x);
-            mfma_j0<K, X1, 1>(c, u.z, b1.x);
-            mfma<in_agpr(0, X1)>(c.acc[0][X1], u.w, b0.y);
-            mfma<in_agpr(1, X1)>(c.acc[1][X1], u.w, b1.y);
-            if constexpr (SQ + URING < NCH * 18) c.ur[SQ % URING] = c.up[(SQ + URING) * 64];
-            PNP_SLOT();
-        }
-        return;
-    }
-    const f32x2 b0 = c.b[0][0], b1 = c.b[0][1];
-    mfma_j0<K, X0, 0>(c, u.x, b0.x);                 PNP_SLOT();          // M1
+    f32x2 b0[NG], b1[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) b0[g] = c.b[0][g];
+    mfma_j0<K, X0, 0>(c, u.x, b0);                   PNP_SLOT();          // M1
     if constexpr (VAR != 13 && VAR != 15) b_load<VPAR, X1, 0>(c);
     PNP_SLOT();
-    mfma_j0<K, X0, 1>(c, u.x, b1.x);                 PNP_SLOT();          // M2
+    mfma_j0<K, X0, 1>(c, u.x, b0);                   PNP_SLOT();          // M2
     if constexpr (VAR != 13 && VAR != 15) b_load<VPAR, X1, 1>(c);
     PNP_SLOT();
-    mfma<in_agpr(0, X0)>(c.acc[0][X0], u.y, b0.y);   PNP_SLOT();          // M3
+    mfma_j1<X0, 0>(c, u.y, b0);                      PNP_SLOT();          // M3
     if constexpr (VAR != 10 && VAR != 15) slice_valu<P>(c);
     PNP_SLOT();
-    mfma<in_agpr(1, X0)>(c.acc[1][X0], u.y, b1.y);   PNP_SLOT();          // M4
+    mfma_j1<X0, 1>(c, u.y, b0);                      PNP_SLOT();          // M4
     if constexpr (VAR != 14 && VAR != 15) slice_lds<DPAR, P, 0>(c);
     PNP_SLOT();
-    const f32x2 c0 = c.b[1][0], c1 = c.b[1][1];
-    mfma_j0<K, X1, 0>(c, u.z, c0.x);                 PNP_SLOT();          // M5
+#pragma unroll
+    for (int g = 0; g < NG; ++g) b1[g] = c.b[1][g];
+    mfma_j0<K, X1, 0>(c, u.z, b1);                   PNP_SLOT();          // M5
     if constexpr (X1 + 1 < 36 && VAR != 13 && VAR != 15) b_load<VPAR, X1 + 1, 0>(c);
     PNP_SLOT();
-    mfma_j0<K, X1, 1>(c, u.z, c1.x);                 PNP_SLOT();          // M6
+    mfma_j0<K, X1, 1>(c, u.z, b1);                   PNP_SLOT();          // M6
     if constexpr (X1 + 1 < 36 && VAR != 13 && VAR != 15) b_load<VPAR, X1 + 1, 1>(c);
     PNP_SLOT();
-    mfma<in_agpr(0, X1)>(c.acc[0][X1], u.w, c0.y);   PNP_SLOT();          // M7
-    if constexpr (P < PPW && VAR != 11 && VAR != 15) dma(P);
+    mfma_j1<X1, 0>(c, u.w, b1);                      PNP_SLOT();          // M7
+    if constexpr (P < CT::G::PPW && VAR != 11 && VAR != 15) dma(P);
     if constexpr (VAR != 14 && VAR != 15) slice_lds<DPAR, P, 1>(c);
     PNP_SLOT();
-    mfma<in_agpr(1, X1)>(c.acc[1][X1], u.w, c1.y);   PNP_SLOT();          // M8
+    mfma_j1<X1, 1>(c, u.w, b1);                      PNP_SLOT();          // M8
     if constexpr (VAR != 14 && VAR != 15) slice_lds<DPAR, P, 2>(c);
     if constexpr (VAR != 12 && VAR != 15 && SQ + URING < NCH * 18) c.ur[SQ % URING] = c.up[(SQ + URING) * 64];
     PNP_SLOT();
 }
-template <int K, int VAR, typename DMA, int... P> __device__ __forceinline__ void chunk_steps(Ctx& c, DMA&& dma, std::integer_sequence<int, P...>) {
+template <int K, int VAR, typename CT, typename DMA, int... P> __device__ __forceinline__ void chunk_steps(CT& c, DMA&& dma, std::integer_sequence<int, P...>) {
     (step<K, P, VAR>(c, dma), ...);
 }
+// weight reloads issued in steps p0 .. 17 of chunk K
+template <int K> constexpr int reloads_from(int p0) {
+    int n = 0;
+    for (int p = p0; p < 18; ++p) n += (K * 18 + p + URING < NCH * 18) ? 1 : 0;
+    return n;
+}
 // chunk K of a tile: MFMAs on V buffer K & 1, transform of chunk K + 1, DMA of chunk K + 2
-template <int K, bool STAMP, int VAR, typename DMA> __device__ __forceinline__ void chunk(Ctx& c, DMA&& dma, unsigned long long& t_wait) {
+template <int K, bool STAMP, int VAR, typename CT, typename DMA> __device__ __forceinline__ void chunk(CT& c, DMA&& dma, unsigned long long& t_wait) {
     patch_load<(K + 1) & 1, 0, 0>(c);
     patch_load<(K + 1) & 1, 0, 1>(c);
     b_load<K & 1, 0, 0>(c);
@@ -276,17 +278,18 @@ template <int K, bool STAMP, int VAR, typename DMA> __device__ __forceinline__ v
     chunk_steps<K, VAR>(c, dma, std::make_integer_sequence<int, 18>{});
     unsigned long long ta = 0;
     if (STAMP) ta = __builtin_amdgcn_s_memtime();
-    // this chunk's DMA pieces have landed: they were issued in steps 0 .. PPW - 1, each before its step's weight load
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(18 - PPW) : "memory");
+    // this chunk's DMA pieces have landed: they were issued in steps 0 .. PPW - 1, each before its step's weight reload, so
+    // at most the reloads of steps PPW .. 17 may still be in flight (the last chunks of a tile reload nothing: see step())
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(reloads_from<K>(CT::G::PPW)) : "memory");
     __syncthreads();
     if (STAMP) t_wait += __builtin_amdgcn_s_memtime() - ta;
 }
-template <bool STAMP, int VAR, typename MK, int... K> __device__ __forceinline__ void all_chunks(Ctx& c, MK&& mk, unsigned long long& t_wait, std::integer_sequence<int, K...>) {
+template <bool STAMP, int VAR, typename CT, typename MK, int... K> __device__ __forceinline__ void all_chunks(CT& c, MK&& mk, unsigned long long& t_wait, std::integer_sequence<int, K...>) {
     (chunk<K, STAMP, VAR>(c, mk(std::integral_constant<int, K>{}), t_wait), ...);
 }
 
 // the first chunk of a workgroup's first tile, outside the pipeline
-__device__ __forceinline__ void transform0(const float* dsrc, float* vdst) {
+template <int VPL> __device__ __forceinline__ void transform0(const float* dsrc, float* vdst) {
     float t[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -304,12 +307,14 @@ __device__ __forceinline__ void transform0(const float* dsrc, float* vdst) {
 
 // STAMP: diagnostic build only (wino44_debug_clock): s_memtime / s_memrealtime around the tile loop, the chunk-end waits and
 // the epilogue; the stamps go to their own buffer
-template <bool LEAKY, bool STAMP = false, int VAR = 0>
+template <bool LEAKY, int NG = 2, bool STAMP = false, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__ in, float* __restrict__ out,
                                                        const float4* __restrict__ upack, const float* __restrict__ bias,
                                                        int H, int W, int ntiles, float slope,
                                                        unsigned long long* __restrict__ stamps = nullptr) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    using G = Geo<NG>;
+    constexpr int TR = G::TR, PR = G::PR, PLANE = G::PLANE, DBUF = G::DBUF, PPW = G::PPW, VPL = G::VPL, VBUF = G::VBUF;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
 
@@ -318,7 +323,8 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
     for (int r = 0; r < 4; ++r) bv[r] = bias[16 * wv + 4 * (lane >> 4) + r];
 
     // transform item of this thread: block (g, tc), chunk channel 2 wv + j  (k-row wv, k-step j of the MFMA B operand)
-    const int tc = lane & 15, j = (lane >> 4) & 1, g = lane >> 5;
+    // (with one block row the upper half-wave repeats the lower half's items: same values to the same addresses)
+    const int tc = lane & 15, j = (lane >> 4) & 1, g = NG == 2 ? lane >> 5 : 0;
     const int d_off = 4 * ((2 * wv + j) * (PLANE / 4) + g * PC + tc);               // 16-byte aligned
     const int v_off = g * 128 + wv * 32 + tc * 2 + j;
 
@@ -364,12 +370,12 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
     float* const dbuf = lds;
     float* const vbuf = lds + 2 * DBUF;
 
-    Ctx c;
+    Ctx<NG> c;
     lds_f* const ldsp = (lds_f*)lds;
     c.dsrc[0] = ldsp + d_off;                     c.dsrc[1] = ldsp + DBUF + d_off;
     c.vdst[0] = ldsp + 2 * DBUF + v_off;          c.vdst[1] = ldsp + 2 * DBUF + VBUF + v_off;
     c.vsrc0[0] = ldsp + 2 * DBUF + 2 * lane;      c.vsrc0[1] = ldsp + 2 * DBUF + VBUF + 2 * lane;
-    c.vsrc1[0] = c.vsrc0[0] + 128;                c.vsrc1[1] = c.vsrc0[1] + 128;
+    c.vsrc1[0] = c.vsrc0[0] + 128;                c.vsrc1[1] = c.vsrc0[1] + 128;             // (block row 1; unused when NG = 1)
     asm volatile("" : "+v"(c.vsrc1[0]), "+v"(c.vsrc1[1]));
     // transformed weights: the same stream of NCH x 18 16-byte loads per lane for every tile, kept URING loads ahead
     c.up = (const __attribute__((address_space(1))) f32x4*)upack + (size_t)(wv * NCH * 18) * 64 + lane;
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
         for (int i = 0; i < URING; ++i) c.ur[i] = c.up[i * 64];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        transform0(dbuf + d_off, vbuf + v_off);
+        transform0<VPL>(dbuf + d_off, vbuf + v_off);
         __syncthreads();
     }
 
@@ -415,10 +421,10 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
         // the asm statements stand, and it hoists the epilogue's v_accvgpr_reads right behind them.  Every accumulator is
         // therefore re-defined here by an empty asm (ordered behind the wait states; no code).
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2)
+        for (int g2 = 0; g2 < NG; ++g2)
 #pragma unroll
             for (int xi = 0; xi < 36; xi += 4) {
-                if (in_agpr(g2, xi)) asm volatile("" : "+a"(c.acc[g2][xi]), "+a"(c.acc[g2][xi + 1]), "+a"(c.acc[g2][xi + 2]), "+a"(c.acc[g2][xi + 3]));
+                if (G::in_agpr(g2, xi)) asm volatile("" : "+a"(c.acc[g2][xi]), "+a"(c.acc[g2][xi + 1]), "+a"(c.acc[g2][xi + 2]), "+a"(c.acc[g2][xi + 3]));
                 else asm volatile("" : "+v"(c.acc[g2][xi]), "+v"(c.acc[g2][xi + 1]), "+v"(c.acc[g2][xi + 2]), "+v"(c.acc[g2][xi + 3]));
             }
         // epilogue: Y = A^T M A, bias, ReLU; a lane holds block (g2, tc) of channels 16 wv + 4 (lane >> 4) + i.  Two
@@ -427,12 +433,12 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
         // M[1][1], whose weight is 1 in all sixteen outputs.
         float* ob = out + ((size_t)b * C + 16 * wv + 4 * (lane >> 4)) * H * W + (size_t)ty0 * W + tx0 + 4 * tc;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
+        for (int blk = 0; blk < 2 * NG; ++blk) {
             {
-                const int g2 = 1 - (blk >> 1), pi = blk & 1;        // block row 1 first: it frees the eight VGPR accumulator quads
+                const int g2 = NG == 2 ? 1 - (blk >> 1) : 0, pi = blk & 1;   // block row 1 first: it frees the eight VGPR accumulator quads
                 // no weight load is in flight across the epilogue (a spilled in-flight load costs its whole latency); the
                 // ring's first entries of the next tile go out before the last block
-                if (blk == 3) {
+                if (blk == 2 * NG - 1) {
 #pragma unroll
                     for (int i = 0; i < URING; ++i) c.ur[i] = c.up[i * 64];
                     __builtin_amdgcn_sched_barrier(0);
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
 
 }  // namespace w44
 
-bool wino44_supports(int H, int W) { return H % w44::TR == 0 && W % w44::TC == 0; }
+bool wino44_supports(int H, int W) { return H % 8 == 0 && W % w44::TC == 0; }
 
 size_t wino44_weight_floats(int n_mid) { return (size_t)n_mid * 4 * w44::NCH * 18 * 64 * 4; }
 
@@ -513,12 +519,21 @@ void wino44_pack_weights(const float* w_mid, int n_mid, float* out) {
 
 int wino44_layer(const float* in, float* out, const float* upack_layer, const float* bias, const float* zeros, int H, int W,
                  int batch, int num_cu, float slope, hipStream_t s) {
-    const int ntiles = batch * (H / w44::TR) * (W / w44::TC);
+    // 8 x 64 regions (72 accumulator quads per wave) unless they would leave CUs idle: then 4 x 64 regions, twice as many
+    // (one 256 x 256 image: 256 instead of 128); PNP_W44_ROWS = 1 / 2 forces a form
+    static const int force = getenv("PNP_W44_ROWS") ? atoi(getenv("PNP_W44_ROWS")) : 0;
+    const int nt2 = batch * (H / 8) * (W / w44::TC);
+    const bool one_row = force == 1 || (force != 2 && nt2 < num_cu);
+    const int ntiles = one_row ? 2 * nt2 : nt2;
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    if (slope != 0.f)
-        w44::k_mid_wino44<true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, slope);
-    else
-        w44::k_mid_wino44<false><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
+    const float4* up = (const float4*)upack_layer;
+    if (one_row) {
+        if (slope != 0.f) w44::k_mid_wino44<true, 1><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, ntiles, slope);
+        else w44::k_mid_wino44<false, 1><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, ntiles, 0.f);
+    } else {
+        if (slope != 0.f) w44::k_mid_wino44<true, 2><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, ntiles, slope);
+        else w44::k_mid_wino44<false, 2><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, ntiles, 0.f);
+    }
     PNP_CHECK_LAUNCH();
     return PNP_OK;
 }
@@ -527,15 +542,15 @@ int wino44_layer(const float* in, float* out, const float* upack_layer, const fl
 // chunk-end waits + barriers, cycles in the epilogue} of the tile loop
 int wino44_debug_clock(const float* in, float* out, const float* upack_layer, const float* bias, int H, int W, int batch,
                        int num_cu, int reps, unsigned long long* stamps_dev, hipStream_t s) {
-    const int ntiles = batch * (H / w44::TR) * (W / w44::TC);
+    const int ntiles = batch * (H / 8) * (W / w44::TC);
     const int grid = ntiles < num_cu ? ntiles : num_cu;
     for (int i = 0; i < reps - 1; ++i)
-        w44::k_mid_wino44<false><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
+        w44::k_mid_wino44<false, 2><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
     const int var = getenv("PNP_W44_VAR") ? atoi(getenv("PNP_W44_VAR")) : 0;
-    if (var == 0) w44::k_mid_wino44<false, true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
+    if (var == 0) w44::k_mid_wino44<false, 2, true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
 #ifdef PNP_W44_ABLATIONS   // timing-only builds (wrong results): 5 = everything in front of each xi's MFMAs, 10 = no transform
                            // arithmetic, 11 = no DMA, 12 = no weight reloads, 13 = no B reads, 14 = no transform LDS traffic, 15 = bare MFMAs
-#define PNP_W44_ABL(V) else if (var == V) w44::k_mid_wino44<false, true, V><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
+#define PNP_W44_ABL(V) else if (var == V) w44::k_mid_wino44<false, 2, true, V><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
     PNP_W44_ABL(5) PNP_W44_ABL(10) PNP_W44_ABL(11) PNP_W44_ABL(12) PNP_W44_ABL(13) PNP_W44_ABL(14) PNP_W44_ABL(15)
 #undef PNP_W44_ABL
 #endif

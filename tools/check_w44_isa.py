@@ -23,15 +23,17 @@ def regs(text):
 
 
 def check(asm_text):
-    """Per kernel instantiation (also (c): m0 is used by the LDS-DMA statements only): (a) exactly 72 accumulator quads, each the destination of exactly 16 MFMAs (an accumulator
+    """Per kernel instantiation (also (c): m0 is used by the LDS-DMA statements only): (a) exactly 72 (36 for the one-block-row form) accumulator quads, each the destination of exactly 16 MFMAs (an accumulator
     that was moved shows up as extra quads with fewer); (b) outside the epilogue no instruction other than an MFMA names an
-    accumulator AGPR (all 256 are accumulators; the 8 VGPR quads are legitimately reused between tiles, (a) covers them)."""
+    accumulator AGPR (the 8 VGPR quads of the two-row form are legitimately reused between tiles, (a) covers them)."""
     problems, kernels = [], 0
     blocks = re.split(r'\n(?=_ZN3pnp3w4412k_mid_wino44[^\n]*:\s)', asm_text)
     for blk in blocks[1:]:
         name = blk.split(':', 1)[0]
-        if not re.search(r'ILb[01]ELb0ELi[05]EEEv', name):         # stamped / ablation builds (timing only) are not checked
+        m = re.search(r'ILb[01]ELi([12])ELb0ELi0EEEv', name)       # <LEAKY, NG, STAMP = false, VAR = 0>: stamped / ablation builds are not checked
+        if not m:
             continue
+        nq = 36 * int(m.group(1))
         lines = blk.split('\n')
         end = next((i for i, l in enumerate(lines) if l.startswith('.Lfunc_end')), len(lines))
         lines = lines[:end]
@@ -42,8 +44,8 @@ def check(asm_text):
                 m = re.search(r'v_mfma_f32_16x16x4_f32 ([av])\[(\d+):(\d+)\]', l)
                 quads[(m.group(1), int(m.group(2)))] = quads.get((m.group(1), int(m.group(2))), 0) + 1
         bad = {k: n for k, n in quads.items() if n != 16}
-        if len(quads) != 72 or bad:
-            problems.append(f'{name}: {len(quads)} accumulator quads (72 expected); MFMA count != 16 for {sorted(bad.items())[:8]}')
+        if len(quads) != nq or bad:
+            problems.append(f'{name}: {len(quads)} accumulator quads ({nq} expected); MFMA count != 16 for {sorted(bad.items())[:8]}')
         agpr = {('a', r) for (cls, r0) in quads if cls == 'a' for r in range(r0, r0 + 4)}
         mf = [i for i, l in enumerate(lines) if 'v_mfma' in l]
         in_epi, n_epi = False, 0

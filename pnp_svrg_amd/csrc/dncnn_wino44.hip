@@ -5,7 +5,8 @@
 //     M_xi = sum_cin U_xi V_xi  (36 multiply-adds per cin for 16 outputs)          Y = A^T M A
 // i.e. ONE QUARTER of the direct form's matrix-core work (F(4,3) along x alone: one half); fp32 throughout.
 //
-// Organisation (one workgroup = 4 waves = one per SIMD, persistent over 8 x 64 output regions in the XCD-aware order):
+// Organisation (one workgroup = 4 waves = one per SIMD, persistent over 8 x 64 output regions in the XCD-aware order; 4 x 64
+// regions with half the accumulators for launches that would leave CUs idle -- Geo<NG> below):
 //   * the 36 transformed-domain products are 36 independent [64 cout] x [64 cin] x [32 blocks] GEMMs; wave wv owns output
 //     channels [16 wv, 16 wv + 16) and keeps ALL 36 x 2 accumulator quads (288 registers) for the region's 2 x 16 blocks;
 //   * input channels go by in chunks of 8: the chunk's (8+2) x 72 halo planes arrive by LDS-DMA, every thread transforms
@@ -13,7 +14,8 @@
 //     writes its 36 values to the V image [xi][row of blocks][k-row][block][k-step], from which a wave's B operands of
 //     one xi are a single conflict-free ds_read_b64 per block row;
 //   * transformed weights do not fit registers (36 x 64 x 64): they stream from L2 in MFMA operand order, one 16-byte
-//     load per lane and xi pair and chunk, each value used by two MFMAs (the two block rows);
+//     load per lane and xi pair and chunk through a ring of 18 loads in flight, each value used by two MFMAs (the two
+//     block rows);
 //   * software pipeline over chunks: while the MFMAs of chunk k run, the same wave transforms chunk k + 1 and the DMA of
 //     chunk k + 2 is in flight; one barrier per chunk.
 #include "common.h"
@@ -96,8 +98,6 @@ template <bool AG> __device__ __forceinline__ void mfma_first(f32x4& acc, float 
 // * weights: plain loads, a ring of URING 16-byte values per lane; the compiler waits for them itself (its counts do not
 //   include the DMA pieces, so its waits are stricter than needed while pieces are in flight, never weaker).
 // * LDS: plain reads / writes, software-pipelined in the source (B operands one xi ahead, patch rows one slice ahead).
-// Order inside group G = 2p + q (one xi: 4 MFMAs) of a chunk:
-//     read B(G + 1) | q = 0: transform slice p (p < 12); q = 1: DMA piece p (p < PPW) | 4 MFMAs | q = 1: reload the ring slot
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float lds_f;
 typedef __attribute__((address_space(3))) f32x2 lds_f2;

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../pnp_svrg_amd/csrc"
 name=$1; expr=$2
 mkdir -p ../lib/ab /tmp/ab_$name
 sed -e "$expr" dncnn_wino44.hip > ./_ab_$name.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -mllvm -pragma-unroll-threshold=200000 -x hip -c ./_ab_$name.hip -o /tmp/ab_$name/w44.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -mllvm -pragma-unroll-threshold=200000 $AB_FLAGS -x hip -c ./_ab_$name.hip -o /tmp/ab_$name/w44.o
 rm -f ./_ab_$name.hip
 objs=$(ls build/*.o | grep -v dncnn_wino44.hip.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ab/$name.so $objs /tmp/ab_$name/w44.o

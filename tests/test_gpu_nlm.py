@@ -59,6 +59,26 @@ def test_nlm_non_multiple_of_tile_and_other_params():
     np.testing.assert_array_equal(out[0].cpu().numpy(), ref)
 
 
+def test_nlm_strip_kernel_equals_lds_kernel():
+    """The reference's configuration (patch 5, distance 5) runs on the register-strip kernel -- in f64 for batches of up to
+    4 images, the LDS-streaming kernel beyond: same arithmetic in the same order, so a ragged 40 x 56 image gives the same
+    bits alone (strip), in a batch of 6 (LDS form) and from the oracle; in f32 (strip at every batch size) a batched image
+    equals its single-image result."""
+    from pnp_svrg_amd import ops
+    rng = np.random.default_rng(3)
+    zb = rng.random((6, 40, 56))
+    sig = np.full(6, 0.07)
+    ref = od.nl_means_2d(zb[2], 0.07, 0.07)
+    one, _ = ops.nlm2d(dev(zb[2:3], torch.float64), sigma_in=dev(sig[:1], torch.float64))
+    six, _ = ops.nlm2d(dev(zb, torch.float64), sigma_in=dev(sig, torch.float64))
+    np.testing.assert_array_equal(one[0].cpu().numpy(), ref)
+    np.testing.assert_array_equal(six[2].cpu().numpy(), ref)
+    one32, _ = ops.nlm2d(dev(zb[2:3], torch.float32), sigma_in=dev(sig[:1], torch.float32))
+    six32, _ = ops.nlm2d(dev(zb, torch.float32), sigma_in=dev(sig, torch.float32))
+    assert torch.equal(one32[0], six32[2])
+    assert np.abs(one32[0].cpu().numpy() - ref).max() <= 2e-4
+
+
 def test_nlm_denoiser_surface(g_denoise):
     import denoisers
     g = g_denoise

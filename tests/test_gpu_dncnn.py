@@ -124,6 +124,25 @@ def test_wino44_shapes_and_edges():
         ops.DncnnPlan(w, 40, 96, 1, winograd=5)
 
 
+def test_wino44_run_to_run_identical(W15):
+    """Repeated forward passes through the F(4x4,3x3) layers are bit-identical, with HBM traffic from a second stream under
+    half of them (a stale accumulator copy, a missed DMA wait or an LDS race would differ from run to run); both region
+    forms (1 image: 4 x 64 regions, 7 images: 8 x 64) and region counts that do not fill the last wave of workgroups."""
+    from pnp_svrg_amd import ops
+    side = torch.cuda.Stream()
+    junk = torch.empty(32 * 1024 * 1024, device='cuda')
+    for B in (1, 7):
+        plan = ops.DncnnPlan(W15, 256, 256, B, winograd=5)
+        x = torch.rand(B, 256, 256, device='cuda')
+        first = plan.forward(x).clone()
+        for i in range(12):
+            if i % 2:
+                with torch.cuda.stream(side):
+                    junk.mul_(1.0001)
+            assert torch.equal(plan.forward(x), first), (B, i)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['SimpleCNN', 'RealSN_SimpleCNN'])
 def test_simplecnn_family(name):

@@ -156,6 +156,7 @@ __device__ __forceinline__ void col_store(const cx<float> (&v)[16], cx<float>* l
 // a, b, c1, c2: THIS image's arrays (wave-uniform pointers -> scalar base + 32-bit lane offset addressing; 64-bit per-lane
 // addresses for five arrays would cost dozens of registers).  No __restrict__ on them: the batches below are ordered by
 // memory clobbers, which the compiler may ignore for loads it knows to be invariant.
+template <int STOP = 0>
 __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const float* a, const float* b,
                                                const uint32_t* __restrict__ bits, const cx<float>* twl, cx<float>* ldc,
                                                uint32_t (*sbits)[2][16], const cx<float>* __restrict__ yh, float scale, float beta,
@@ -189,11 +190,13 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
             asm volatile("" ::: "memory");
         }
     }
+    if (STOP == 10) return;                                 // (diagnostic: the operand loads of phase 1 alone)
 #pragma unroll
     for (int p = 0; p < FP; ++p) {
         fft256<false>(Z[p], twl, scr, l);
         asm volatile("" ::: "memory");
     }
+    if (STOP == 1) return;
 
     // ------------------------------------------------------------------ 2: columns, two halves
 #pragma unroll
@@ -240,6 +243,7 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
             }
     }
     __syncthreads();
+    if (STOP == 2) return;
 
     // ------------------------------------------------------------------ 3: rows inverse + epilogue (in place in Z)
     // same budget: the four inverse transforms first, then the epilogue operands two row pairs at a time
@@ -286,7 +290,8 @@ namespace pnp {
 // MODE: 0 = the whole iteration; 1 = stop after the noise estimate and store the stepped image (another prox follows);
 //       2 = the gradient only (phases 1-3, stored in row order: grad_full with its data term, or any other use of
 //           pnp_csmri_grad_sel that fits this kernel).
-// STOP (diagnostic builds, PNP_FUSED_STOP): leave after phase STOP with a checksum store, to time the phases one by one
+// STOP (diagnostic builds, PNP_FUSED_STOP): leave after phase STOP (10 = after the operand loads of phase 1) with a checksum
+// store, to time the phases one by one
 enum { FUSED_FULL = 0, FUSED_NO_DENOISE = 1, FUSED_GRAD = 2 };
 template <int MODE, int STOP>
 __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b,
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     __syncthreads();
 
     cx<float> Z[FP][16];
-    fused_gradient(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twl, ldc, sbits,
+    fused_gradient<(STOP == 1 || STOP == 2 || STOP == 10) ? STOP : 0>(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twl, ldc, sbits,
                    yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
                    c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l);
     if (MODE == FUSED_GRAD) {
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
         }
         return;
     }
-    if (STOP == 3) {
+    if (STOP == 3 || STOP == 1 || STOP == 2 || STOP == 10) {
         float acc = 0.f;
 #pragma unroll
         for (int p = 0; p < FP; ++p)
@@ -455,6 +460,9 @@ int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* 
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
         attr_done |= 1ull << (dev & 63);
     }
 #define PNP_FUSED_LAUNCH(MD, ST)                                                                                          \
@@ -464,6 +472,9 @@ int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* 
                                                        (float)sigma_modifier, (float)fallback_sigma, (const float*)xrec,      \
                                                        sse_out, (float*)sigma_out)
     if (mode == FUSED_GRAD) PNP_FUSED_LAUNCH(2, 0);
+    else if (stop == 1) PNP_FUSED_LAUNCH(0, 1);
+    else if (stop == 2) PNP_FUSED_LAUNCH(0, 2);
+    else if (stop == 10) PNP_FUSED_LAUNCH(0, 10);
     else if (stop == 3) PNP_FUSED_LAUNCH(0, 3);
     else if (stop == 4) PNP_FUSED_LAUNCH(0, 4);
     else if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0, 0);

@@ -11,7 +11,7 @@ sel = torch.empty((1, B, 256, 8), dtype=torch.int32, device='cuda')
 p.draw_thresholds(b.bits, 1000, 1, 0, 1, selbits=sel)
 sse = torch.empty(B, dtype=torch.float64, device='cuda')
 out = torch.empty_like(z)
-for stop in (3, 4, 0):
+for stop in (10, 1, 2, 3, 4, 0):
     os.environ['PNP_FUSED_STOP'] = str(stop)
     for _ in range(3):
         p.svrg_step(z, w, sel[0], alpha=-2.0, beta=1.0, c1=z, gamma=-2e3, c2=mu, out=out, xrec=b.xrec, sse=sse)
@@ -21,4 +21,4 @@ for stop in (3, 4, 0):
     for _ in range(30):
         p.svrg_step(z, w, sel[0], alpha=-2.0, beta=1.0, c1=z, gamma=-2e3, c2=mu, out=out, xrec=b.xrec, sse=sse)
     e1.record(); torch.cuda.synchronize()
-    print(f'stop after phase {stop or 5}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per launch (B = {B})')
+    print(f'stop after phase {"1 (loads only)" if stop == 10 else (stop or 5)}: {e0.elapsed_time(e1) / 30 * 1e3:.1f} us per launch (B = {B})')

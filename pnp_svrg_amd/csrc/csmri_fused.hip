@@ -159,9 +159,20 @@ __device__ __forceinline__ void col_store(const cx<float> (&v)[16], cx<float>* l
 template <int STOP = 0>
 __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const float* a, const float* b,
                                                const uint32_t* __restrict__ bits, const cx<float>* twl, cx<float>* ldc,
-                                               uint32_t (*sbits)[2][16], const cx<float>* __restrict__ yh, float scale, float beta,
+                                               uint32_t (*sbits)[FG][2][16], const cx<float>* __restrict__ yh, float scale, float beta,
                                                const float* c1, float gamma, const float* c2, int g, int l) {
     cx<float>* scr = ldc + g * F_SCR;
+    // selector bits of this group's four column pairs (two per half): fetched now, under the operand loads of phase 1 --
+    // inside phase 2 their round trip to L2 sat exposed between two workgroup barriers, once per half
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = k * FG + g;
+            const int ca = half == 0 ? idx : 64 + idx;
+            const int cb = (half == 0 && idx == 0) ? 128 : FN - ca;
+            sbits[half][g][k][l] = bits[(size_t)(l < 8 ? ca : cb) * 8 + (l & 7)];
+        }
     unsigned off[FP];                                       // element offset of (row 2rp, column l); row 2rp+1 is +FN
 #pragma unroll
     for (int p = 0; p < FP; ++p) off[p] = (unsigned)(2 * (p * FG + g)) * FN + l;
@@ -220,16 +231,15 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
             const bool packed = half == 0 && idx == 0;      // columns 0 and 128
             const int cb = packed ? 128 : FN - ca;
             cp[k] = {kx_local(ca, half), kx_local(cb, half), packed};
-            sbits[g][k][l] = bits[(size_t)(l < 8 ? ca : cb) * 8 + (l & 7)];
         }
         __syncthreads();
         cx<float> v0[16], v1[16];
         col_load(v0, ldc, cp[0], l);
         col_load(v1, ldc, cp[1], l);
         __syncthreads();                                    // every group has its columns: the buffer becomes FFT scratch
-        col_transform(v0, twl, scr, sbits[g][0], cp[0], l, yhc[0]);
+        col_transform(v0, twl, scr, sbits[half][g][0], cp[0], l, yhc[0]);
         asm volatile("" ::: "memory");                      // one transform's working registers at a time
-        col_transform(v1, twl, scr, sbits[g][1], cp[1], l, yhc[1]);
+        col_transform(v1, twl, scr, sbits[half][g][1], cp[1], l, yhc[1]);
         __syncthreads();                                    // all FFT scratch use is over: the buffer carries data again
         col_store(v0, ldc, cp[0], l);
         col_store(v1, ldc, cp[1], l);
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     cx<float>* ldc = reinterpret_cast<cx<float>*>(lds_raw);
     float* ldf = reinterpret_cast<float*>(lds_raw);
     __shared__ cx<float> twl[FN];
-    __shared__ uint32_t sbits[FG][2][16];
+    __shared__ uint32_t sbits[2][FG][2][16];
     __shared__ double red[8];
     __shared__ float sig_sh;
     const int t = threadIdx.x, g = t >> 4, l = t & 15, wv = t >> 6, lane64 = t & 63;

@@ -158,7 +158,7 @@ __device__ __forceinline__ void col_store(const cx<float> (&v)[16], cx<float>* l
 // memory clobbers, which the compiler may ignore for loads it knows to be invariant.
 template <int STOP = 0>
 __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const float* a, const float* b,
-                                               const uint32_t* __restrict__ bits, const cx<float>* twl, cx<float>* ldc,
+                                               const uint32_t* __restrict__ bits, const cx<float>* __restrict__ twtab, cx<float>* twl, cx<float>* ldc,
                                                uint32_t (*sbits)[FG][2][16], const cx<float>* __restrict__ yh, float scale, float beta,
                                                const float* c1, float gamma, const float* c2, int g, int l) {
     cx<float>* scr = ldc + g * F_SCR;
@@ -173,6 +173,8 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
             const int cb = (half == 0 && idx == 0) ? 128 : FN - ca;
             sbits[half][g][k][l] = bits[(size_t)(l < 8 ? ca : cb) * 8 + (l & 7)];
         }
+    cx<float> twv = {0.f, 0.f};
+    if ((int)threadIdx.x < FN) twv = twtab[threadIdx.x];
     unsigned off[FP];                                       // element offset of (row 2rp, column l); row 2rp+1 is +FN
 #pragma unroll
     for (int p = 0; p < FP; ++p) off[p] = (unsigned)(2 * (p * FG + g)) * FN + l;
@@ -201,6 +203,9 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
             asm volatile("" ::: "memory");
         }
     }
+    // twiddles: requested before the operands (twv above), landed with them; the barrier also orders the selector bits
+    if ((int)threadIdx.x < FN) twl[threadIdx.x] = twv;
+    __syncthreads();
     if (STOP == 10) return;                                 // (diagnostic: the operand loads of phase 1 alone)
 #pragma unroll
     for (int p = 0; p < FP; ++p) {
@@ -322,12 +327,11 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     const int t = threadIdx.x, g = t >> 4, l = t & 15, wv = t >> 6, lane64 = t & 63;
     const int prob = blockIdx.x;
     const size_t img = (size_t)prob * FN * FN;
-    if (t < FN) twl[t] = twtab[t];
+    // (the twiddle table goes to LDS inside fused_gradient, under the operand loads of phase 1)
     if (alpha_vec != nullptr) scale *= alpha_vec[prob];
-    __syncthreads();
 
     cx<float> Z[FP][16];
-    fused_gradient<(STOP == 1 || STOP == 2 || STOP == 10) ? STOP : 0>(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twl, ldc, sbits,
+    fused_gradient<(STOP == 1 || STOP == 2 || STOP == 10) ? STOP : 0>(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
                    yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
                    c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l);
     if (MODE == FUSED_GRAD) {

@@ -132,7 +132,7 @@ template <int NG_> struct Ctx {
 //     M5 | B(xi0')[0] | M6 | B(xi0')[1] | M7 | DMA piece p, slice LDS op 2 | M8 | slice LDS op 3, ring reload
 #define PNP_SLOT() __builtin_amdgcn_sched_barrier(0)
 
-// patch row R of d buffer DPAR, in two halves; all ten floats are "used" (patch_rows) so that the reads stay one
+// patch row R of d buffer DPAR, in two halves; all ten floats are "used" (slice_valu) so that the reads stay one
 // conflict-free ds_read_b128 and two ds_read_b64 (narrowed to the six needed values they become three 4-way
 // bank-conflicting ds_read2_b32)
 template <int DPAR, int R, int HALF, typename CT> __device__ __forceinline__ void patch_load(CT& c) {
@@ -548,10 +548,10 @@ int wino44_debug_clock(const float* in, float* out, const float* upack_layer, co
         w44::k_mid_wino44<false, 2><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f);
     const int var = getenv("PNP_W44_VAR") ? atoi(getenv("PNP_W44_VAR")) : 0;
     if (var == 0) w44::k_mid_wino44<false, 2, true><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
-#ifdef PNP_W44_ABLATIONS   // timing-only builds (wrong results): 5 = everything in front of each xi's MFMAs, 10 = no transform
+#ifdef PNP_W44_ABLATIONS   // timing-only builds (wrong results): 10 = no transform
                            // arithmetic, 11 = no DMA, 12 = no weight reloads, 13 = no B reads, 14 = no transform LDS traffic, 15 = bare MFMAs
 #define PNP_W44_ABL(V) else if (var == V) w44::k_mid_wino44<false, 2, true, V><<<grid, 256, 0, s>>>(in, out, (const float4*)upack_layer, bias, H, W, ntiles, 0.f, stamps_dev);
-    PNP_W44_ABL(5) PNP_W44_ABL(10) PNP_W44_ABL(11) PNP_W44_ABL(12) PNP_W44_ABL(13) PNP_W44_ABL(14) PNP_W44_ABL(15)
+    PNP_W44_ABL(10) PNP_W44_ABL(11) PNP_W44_ABL(12) PNP_W44_ABL(13) PNP_W44_ABL(14) PNP_W44_ABL(15)
 #undef PNP_W44_ABL
 #endif
     else PNP_CHECK_ARG(false, "PNP_W44_VAR: this library was built without -DPNP_W44_ABLATIONS");

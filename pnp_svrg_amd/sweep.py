@@ -73,7 +73,7 @@ def _csmri_item_generator(img, it, H, W):
 
 
 def csmri_svrg_runner(images, denoiser_factory, eta, T2, mini_batch_size, n_inner, H=256, W=256, dtype=torch.float32,
-                      max_batch=128, seeding='generator', algorithm='svrg', variant='svrg', run_seed=1, keep_trace=False):
+                      max_batch=128, seeding='generator', algorithm='svrg', variant='svrg', run_seed=1, keep_trace=False, graph=True):
     """Default runner: CSMRI + pnp_svrg (true SVRG direction) on the batched engine.
     images: list of HxW arrays.  ALL of a rank's items -- any mix of sampling ratios, i.e. masks with different
     numbers of sampled points -- go through the engine together (chunks of max_batch): per-problem 1/M0 and
@@ -82,7 +82,8 @@ def csmri_svrg_runner(images, denoiser_factory, eta, T2, mini_batch_size, n_inne
     seeding='legacy'   : per item exactly what the reference does -- np.random.seed(item seed), the CSMRI constructor's
                          draws in its order (mask, noise; problems/CSMRI.py:12-41), then np.random.seed(run_seed) and one
                          select_mb draw per inner iteration (algorithms/pnp_svrg.py:52) from the legacy stream -- so an
-                         item's trajectory equals the reference loop's (and the oracle's) on the same seeds."""
+                         item's trajectory equals the reference loop's (and the oracle's) on the same seeds.
+    graph=False steps eagerly where whole outer iterations would otherwise replay as hipGraphs (same results)."""
     from .engine import CsmriBatch, make_engine
     from . import problems as P
 
@@ -108,8 +109,14 @@ def csmri_svrg_runner(images, denoiser_factory, eta, T2, mini_batch_size, n_inne
             eng = make_engine(batch, denoiser_factory(), eta, T2, mini_batch_size, variant=variant, algorithm=algorithm,
                               seed=chunk[0]['id'] + 1)
             idx_d = torch.from_numpy(idx).to(batch.device) if idx is not None else None
-            for s in range(n_inner):
-                eng.step(idx_d[s]) if idx_d is not None else eng.step()
+            # device-drawn minibatches: whole outer iterations replay as hipGraphs (bit-identical to stepping; a rank's share
+            # of a sweep is a small batch, where the ~25 launches of an inner iteration are a tenth of its time)
+            if (graph and idx_d is None and hasattr(eng, 'run_outer') and n_inner % T2 == 0 and n_inner > T2
+                    and getattr(eng, 'lr_decay', 1.0) == 1.0 and getattr(eng.prox, 'denoise_strength', 0.0) == 0.0):
+                eng.run_outer(n_inner // T2)
+            else:
+                for s in range(n_inner):
+                    eng.step(idx_d[s]) if idx_d is not None else eng.step()
             tr = eng.psnr_trace()
             psnr0 = batch.psnr_init()
             z = eng.z.cpu().numpy()

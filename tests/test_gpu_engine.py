@@ -324,6 +324,11 @@ def test_sweep_runner_single_process():
     assert res[0]['psnr_final'] > res[0]['psnr_init']          # 20 % sampling: the reconstruction helps
     # more samples -> better reconstruction of the same image
     assert res[2]['psnr_final'] > res[0]['psnr_final']
+    # the runner replays whole outer iterations as hipGraphs (device-drawn minibatches): same bits as eager stepping
+    eager = sweep.run_sweep(items, sweep.csmri_svrg_runner(imgs, lambda: TVProx(), eta=5e2, T2=4, mini_batch_size=100, n_inner=12,
+                                                           H=64, W=64, graph=False))
+    for a, b in zip(res, eager):
+        assert np.array_equal(a['z'], b['z']) and a['psnr_final'] == b['psnr_final']
 
 
 def test_grid_search_on_device(tmp_path):

@@ -311,12 +311,22 @@ template <bool LEAKY, int NG = 2, bool STAMP = false, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__ in, float* __restrict__ out,
                                                        const float4* __restrict__ upack, const float* __restrict__ bias,
                                                        int H, int W, int ntiles, float slope,
-                                                       unsigned long long* __restrict__ stamps = nullptr) {
+                                                       unsigned long long* __restrict__ stamps = nullptr, int tile0 = 0) {
     using G = Geo<NG>;
     constexpr int TR = G::TR, PR = G::PR, PLANE = G::PLANE, DBUF = G::DBUF, PPW = G::PPW, VPL = G::VPL, VBUF = G::VBUF;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = W / TC, tiles_per_img = tiles_x * (H / TR);
+    // Regions are numbered in units of 8 x 64 pixels (`tile0` + ...) whatever the form: a 4 x 64 region u is sub-row u & 1 of
+    // unit tile0 + (u >> 1), so that a launch of the one-row form can take over the units a two-row launch left (the last,
+    // partly filled wave of workgroups: wino44_layer)
+    const int tiles_x = W / TC, units_per_img = tiles_x * (H / 8);
+    auto region = [&](int u, int& b, int& ty0, int& tx0) {
+        const int t = tile0 + (NG == 2 ? u : u >> 1);
+        b = t / units_per_img;
+        const int t2 = t - b * units_per_img;
+        ty0 = (t2 / tiles_x) * 8 + (NG == 2 ? 0 : 4 * (u & 1));
+        tx0 = (t2 % tiles_x) * TC;
+    };
 
     float bv[4];
 #pragma unroll
@@ -347,8 +357,8 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
     const size_t chunk_bytes = (size_t)KC * H * W * 4;
     auto tile_dma = [&](int t) {
         TileDma td;
-        const int b = t / tiles_per_img, t2 = t - b * tiles_per_img;
-        const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
+        int b, ty0, tx0;
+        region(t, b, ty0, tx0);
         td.base = (size_t)in + 4 * ((((size_t)b * C) * H + ty0 - 1) * (size_t)W + tx0 - 4);
         const unsigned bad = t < ntiles ? ((((ty0 == 0 ? 1u : 0u) | (ty0 + TR == H ? 2u : 0u) | (tx0 == 0 ? 4u : 0u) | (tx0 + TC == W ? 8u : 0u)) << 28) | DUMMY)
                                         : 0xFFFFFFFFu;
@@ -401,8 +411,8 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
     if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (; tile < limit; tile += tw_.step) {
         asm volatile("" : "+v"(c.up));                                          // the weight loads stay inside the tile loop
-        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
-        const int ty0 = (t2 / tiles_x) * TR, tx0 = (t2 % tiles_x) * TC;
+        int b, ty0, tx0;
+        region(tile, b, ty0, tx0);
         const int ntile = tile + tw_.step < limit ? tile + tw_.step : ntiles;      // ntiles = "none": zeros
 
         const TileDma cur = tile_dma(tile), nxt = tile_dma(ntile);
@@ -519,22 +529,27 @@ void wino44_pack_weights(const float* w_mid, int n_mid, float* out) {
 
 int wino44_layer(const float* in, float* out, const float* upack_layer, const float* bias, const float* zeros, int H, int W,
                  int batch, int num_cu, float slope, hipStream_t s) {
-    // 8 x 64 regions (72 accumulator quads per wave) unless they would leave CUs idle: then 4 x 64 regions, twice as many
-    // (one 256 x 256 image: 256 instead of 128); PNP_W44_ROWS = 1 / 2 forces a form
+    // 8 x 64 regions (72 accumulator quads per wave) in full waves of one region per CU; what is left -- a launch smaller than
+    // the chip, or the last, partly filled wave -- goes through the 4 x 64 form, twice as many regions of half the work (one
+    // 256 x 256 image: 256 regions instead of 128; three images: 256 + 256 instead of 384 in two waves).  Same bits either way.
+    // PNP_W44_ROWS = 1 / 2 forces a form for the whole layer.
     static const int force = getenv("PNP_W44_ROWS") ? atoi(getenv("PNP_W44_ROWS")) : 0;
-    const int nt2 = batch * (H / 8) * (W / w44::TC);
-    const bool one_row = force == 1 || (force != 2 && nt2 < num_cu);
-    const int ntiles = one_row ? 2 * nt2 : nt2;
-    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    const int units = batch * (H / 8) * (W / w44::TC);
+    int full = force == 1 ? 0 : force == 2 ? units : (units / num_cu) * num_cu;              // units done as 8 x 64 regions
+    if (force == 0 && 2 * (units - full) > num_cu) full = units;      // (more than half a wave left: one more 8 x 64 wave is cheaper than two 4 x 64 waves)
     const float4* up = (const float4*)upack_layer;
-    if (one_row) {
-        if (slope != 0.f) w44::k_mid_wino44<true, 1><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, ntiles, slope);
-        else w44::k_mid_wino44<false, 1><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, ntiles, 0.f);
-    } else {
-        if (slope != 0.f) w44::k_mid_wino44<true, 2><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, ntiles, slope);
-        else w44::k_mid_wino44<false, 2><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, ntiles, 0.f);
+    if (full > 0) {
+        const int grid = full < num_cu ? full : num_cu;
+        if (slope != 0.f) w44::k_mid_wino44<true, 2><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, full, slope, nullptr, 0);
+        else w44::k_mid_wino44<false, 2><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, full, 0.f, nullptr, 0);
+        PNP_CHECK_LAUNCH();
     }
-    PNP_CHECK_LAUNCH();
+    if (full < units) {
+        const int n1 = 2 * (units - full), grid = n1 < num_cu ? n1 : num_cu;
+        if (slope != 0.f) w44::k_mid_wino44<true, 1><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, n1, slope, nullptr, full);
+        else w44::k_mid_wino44<false, 1><<<grid, 256, 0, s>>>(in, out, up, bias, H, W, n1, 0.f, nullptr, full);
+        PNP_CHECK_LAUNCH();
+    }
     return PNP_OK;
 }
 

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pnp_svrg_amd import ops
 W = dict(np.load(os.path.join(ROOT, 'tests/golden/dncnn_noise15.npz')))
-for B in (2, 4, 6, 8, 12, 16, 24, 40, 60, 120):
+for B in (1, 2, 3, 5, 7, 9, 15, 24, 120):
     plan = ops.DncnnPlan(W, 256, 256, B, winograd=5)
     x = torch.rand(B, 256, 256, device='cuda'); out = torch.empty_like(x)
     for _ in range(3): plan.forward(x, out)

@@ -124,7 +124,16 @@ template <int NG_> struct Ctx {
     lds_f* vdst[2];                                            // its V item in the two V buffers
     const lds_f* vsrc0[2];                                     // its B operands (block row 0 / 1) in the two V buffers;
     const lds_f* vsrc1[2];                                     //   separate, laundered bases: no ds_read2st64_b64 merging
-    const __attribute__((address_space(1))) f32x4* up;         // weight stream of this lane
+    // weight stream of this wave: a scalar cursor (1 KiB per load; advanced on the scalar ALU, re-defined through an empty asm so
+    // that it stays ONE register pair instead of 144 hoisted addresses) + the lane's 16 bytes as a 32-bit vector offset
+    const __attribute__((address_space(1))) char* ucur;
+    unsigned ulane;
+    __device__ __forceinline__ f32x4 uload_next() {
+        const f32x4 u = *(const __attribute__((address_space(1))) f32x4*)(ucur + ulane);
+        ucur += 1024;
+        asm volatile("" : "+s"(ucur));
+        return u;
+    }
 };
 // One LDS read beside an f32 MFMA is free, two in the same gap cost about an MFMA (tools/microbench/mfma_f32_fillers.hip),
 // and vector-ALU work is cheapest in blocks; so a step (two xi = 8 MFMAs) has fixed slots, pinned by sched_barriers:
@@ -180,8 +189,12 @@ template <int SL, typename CT> __device__ __forceinline__ void slice_valu(CT& c)
         const f32x2 Bv = p34 - p12;                               // (sd, t3)
         P.t[SL][1] = pk_sum_diff(A);
         P.t[SL][2] = pk_hi_pm_2lo(Bv);
-        P.t[SL][0].x = __builtin_fmaf(4.f, P.a.y, __builtin_fmaf(-5.f, P.m.y, P.m.w));
-        P.t[SL][0].y = __builtin_fmaf(4.f, P.m.x, __builtin_fmaf(-5.f, P.m.z, P.e.x));
+        // (the last FMA of each as asm with its own destination: hipcc picks the two-address v_fmac_f32 and then moves the
+        //  result into the pair)
+        float v0, v5;
+        asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(v0) : "v"(P.a.y), "v"(__builtin_fmaf(-5.f, P.m.y, P.m.w)));
+        asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(v5) : "v"(P.m.x), "v"(__builtin_fmaf(-5.f, P.m.z, P.e.x)));
+        P.t[SL][0] = f32x2{v0, v5};
     } else if constexpr (is_col_slice(SL)) {
         constexpr int cp = col_pair(SL);
         bt6_pk(P.t[0][cp], P.t[1][cp], P.t[2][cp], P.t[3][cp], P.t[4][cp], P.t[5][cp], P.v);
@@ -256,7 +269,7 @@ template <int K, int P, int VAR, typename CT, typename DMA> __device__ __forcein
     PNP_SLOT();
     mfma_j1<X1, 1>(c, u.w, b1);                      PNP_SLOT();          // M8
     if constexpr (VAR != 14 && VAR != 15) slice_lds<DPAR, P, 2>(c);
-    if constexpr (VAR != 12 && VAR != 15 && SQ + URING < NCH * 18) c.ur[SQ % URING] = c.up[(SQ + URING) * 64];
+    if constexpr (VAR != 12 && VAR != 15 && SQ + URING < NCH * 18) c.ur[SQ % URING] = c.uload_next();
     PNP_SLOT();
 }
 template <int K, int VAR, typename CT, typename DMA, int... P> __device__ __forceinline__ void chunk_steps(CT& c, DMA&& dma, std::integer_sequence<int, P...>) {
@@ -336,6 +349,8 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
     // (with one block row the upper half-wave repeats the lower half's items: same values to the same addresses)
     const int tc = lane & 15, j = (lane >> 4) & 1, g = NG == 2 ? lane >> 5 : 0;
     const int d_off = 4 * ((2 * wv + j) * (PLANE / 4) + g * PC + tc);               // 16-byte aligned
+    const ptrdiff_t hw4 = (ptrdiff_t)4 * H * W, w4 = (ptrdiff_t)4 * W;
+    const unsigned st_off = 4u * (unsigned)(4 * (lane >> 4) * H * W + 4 * tc);      // output: channel 4 (lane >> 4) of the wave's 16, column 4 tc
     const int v_off = g * 128 + wv * 32 + tc * 2 + j;
 
     // DMA piece descriptors: bits 0..26 = element offset of the lane's 16-byte chunk inside the chunk's 8 channel planes,
@@ -388,7 +403,9 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
     c.vsrc1[0] = c.vsrc0[0] + 128;                c.vsrc1[1] = c.vsrc0[1] + 128;             // (block row 1; unused when NG = 1)
     asm volatile("" : "+v"(c.vsrc1[0]), "+v"(c.vsrc1[1]));
     // transformed weights: the same stream of NCH x 18 16-byte loads per lane for every tile, kept URING loads ahead
-    c.up = (const __attribute__((address_space(1))) f32x4*)upack + (size_t)(wv * NCH * 18) * 64 + lane;
+    const __attribute__((address_space(1))) char* const ubase = (const __attribute__((address_space(1))) char*)upack + (size_t)(wv * NCH * 18) * 1024;
+    c.ucur = ubase;
+    c.ulane = 16u * lane;
 
     const TileWalk tw_ = tile_walk(ntiles);
     int tile = tw_.first;
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma_piece(td0, chunk_rsrc(td0, 1), 1, i);
 #pragma unroll
-        for (int i = 0; i < URING; ++i) c.ur[i] = c.up[i * 64];
+        for (int i = 0; i < URING; ++i) c.ur[i] = c.uload_next();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         transform0<VPL>(dbuf + d_off, vbuf + v_off);
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
     unsigned long long t0 = 0, r0 = 0, t_wait = 0, t_epi = 0;
     if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (; tile < limit; tile += tw_.step) {
-        asm volatile("" : "+v"(c.up));                                          // the weight loads stay inside the tile loop
+        asm volatile("" : "+v"(c.ulane));                                        // the weight loads stay inside the tile loop
         int b, ty0, tx0;
         region(tile, b, ty0, tx0);
         const int ntile = tile + tw_.step < limit ? tile + tw_.step : ntiles;      // ntiles = "none": zeros
@@ -441,7 +458,10 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
         // channels at a time on the packed-f32 ALU (the halves of an accumulator quad are register pairs), one column /
         // row per scheduling region so that at most a dozen accumulator copies are in flight; the bias enters through
         // M[1][1], whose weight is 1 in all sixteen outputs.
-        float* ob = out + ((size_t)b * C + 16 * wv + 4 * (lane >> 4)) * H * W + (size_t)ty0 * W + tx0 + 4 * tc;
+        // stores: scalar base (tile, wave, channel pair, row: scalar ALU) + the lane's 32-bit byte offset
+        unsigned so = st_off;                 // (re-defined inside the loop: its zero-extension must sit next to the stores for
+        asm volatile("" : "+v"(so));          //  instruction selection to fold it into the scalar-base addressing mode)
+        __attribute__((address_space(1))) char* const ob = (__attribute__((address_space(1))) char*)out + 4 * ((((size_t)b * C + 16 * wv) * H + ty0) * (size_t)W + tx0);
 #pragma unroll
         for (int blk = 0; blk < 2 * NG; ++blk) {
             {
@@ -449,11 +469,16 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
                 // no weight load is in flight across the epilogue (a spilled in-flight load costs its whole latency); the
                 // ring's first entries of the next tile go out before the last block
                 if (blk == 2 * NG - 1) {
+                    c.ucur = ubase;
 #pragma unroll
-                    for (int i = 0; i < URING; ++i) c.ur[i] = c.up[i * 64];
+                    for (int i = 0; i < URING; ++i) c.ur[i] = c.uload_next();
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const f32x2 bias2 = {bv[2 * pi], bv[2 * pi + 1]};
+                // store cursor: one scalar register pair walked over the block's eight rows (re-defined through empty asms: left
+                // alone, hipcc keeps all 32 store bases in scalar registers and spills them)
+                __attribute__((address_space(1))) char* oc = ob + (ptrdiff_t)(2 * pi) * hw4 + (ptrdiff_t)(4 * g2) * w4;
+                asm volatile("" : "+s"(oc));
                 f32x2 s[6][4];                                  // s[x][r]: A^T along y of column x
 #pragma unroll
                 for (int x = 0; x < 6; ++x) {
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
                 for (int r = 0; r < 4; ++r) {
                     f32x2 y[4];
                     at6(s[0][r], s[1][r], s[2][r], s[3][r], s[4][r], s[5][r], y);
-                    float4 v0, v1;
+                    f32x4 v0, v1;
                     if (LEAKY) {
                         v0.x = fmaxf(y[0].x, slope * y[0].x); v0.y = fmaxf(y[1].x, slope * y[1].x);
                         v0.z = fmaxf(y[2].x, slope * y[2].x); v0.w = fmaxf(y[3].x, slope * y[3].x);
@@ -481,8 +506,12 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44(const float* __restrict__
                         v0.x = fmaxf(y[0].x, 0.f); v0.y = fmaxf(y[1].x, 0.f); v0.z = fmaxf(y[2].x, 0.f); v0.w = fmaxf(y[3].x, 0.f);
                         v1.x = fmaxf(y[0].y, 0.f); v1.y = fmaxf(y[1].y, 0.f); v1.z = fmaxf(y[2].y, 0.f); v1.w = fmaxf(y[3].y, 0.f);
                     }
-                    *reinterpret_cast<float4*>(ob + (size_t)(2 * pi) * H * W + (4 * g2 + r) * W) = v0;
-                    *reinterpret_cast<float4*>(ob + (size_t)(2 * pi + 1) * H * W + (4 * g2 + r) * W) = v1;
+                    *(__attribute__((address_space(1))) f32x4*)(oc + so) = v0;          // channel 2 pi, row 4 g2 + r
+                    oc += hw4;
+                    asm volatile("" : "+s"(oc));
+                    *(__attribute__((address_space(1))) f32x4*)(oc + so) = v1;          // channel 2 pi + 1
+                    oc += w4 - hw4;
+                    asm volatile("" : "+s"(oc));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../pnp_svrg_amd/csrc"
 name=$1; expr=$2; file=${3:-dncnn_wino44.hip}
 mkdir -p ../lib/ab /tmp/ab_$name
 extra=""
-[ "$file" = dncnn_wino44.hip ] && extra="-mllvm -pragma-unroll-threshold=200000"
+[ "$file" = dncnn_wino44.hip ] && extra="-mllvm -pragma-unroll-threshold=200000 -fno-slp-vectorize"
 [ "$file" = prox.hip ] || [ "$file" = nlm.hip ] && extra="-ffp-contract=off"
 if [ -n "$AB_HEADER" ]; then
   mkdir -p /tmp/ab_$name/inc && cp *.h /tmp/ab_$name/inc/ && sed -e "$expr" $AB_HEADER > /tmp/ab_$name/inc/$AB_HEADER

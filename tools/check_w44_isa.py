@@ -79,7 +79,7 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, 'w44.s')
             subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-mllvm',
-                            '-pragma-unroll-threshold=200000', '-x', 'hip', '--cuda-device-only', '-S', SRC, '-o', out],
+                            '-pragma-unroll-threshold=200000', '-fno-slp-vectorize', '-x', 'hip', '--cuda-device-only', '-S', SRC, '-o', out],
                            check=True, stderr=subprocess.DEVNULL)
             text = open(out).read()
     kernels, problems = check(text)

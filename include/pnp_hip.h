@@ -270,6 +270,13 @@ int pnp_saga_table_update(void* z, const void* g, void* slot, const void* prev, 
 int pnp_axpbypcz(double a, const void* x, double b, const void* y, double c, const void* w,
                  void* out, size_t n, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ host: the legacy RNG draw of select_mb
+ * np.random.choice(pool, size, replace=False) (problems/CSMRI.py:72, problems/problem.py:114) on the legacy MT19937 stream,
+ * restated in C (no device work): out[k] = pool[perm[k]] (pool NULL: perm[k]) for the first `size` entries of
+ * permutation(pop).  mt_key [624] / *mt_pos are the stream's state as np.random.get_state() returns it and are advanced
+ * exactly as NumPy advances them; work: [pop] scratch.                                                               */
+int pnp_legacy_choice(uint32_t* mt_key, int* mt_pos, const int64_t* pool, int pop, int size, int32_t* work, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

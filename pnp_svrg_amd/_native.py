@@ -64,6 +64,7 @@ SIGNATURES = {
     'pnp_indicator_from_indices': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'pnp_saga_table_update': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _sz, _i, _vp]),
     'pnp_axpbypcz': (_i, [_d, _vp, _d, _vp, _d, _vp, _vp, _sz, _i, _vp]),
+    'pnp_legacy_choice': (_i, [_vp, ctypes.POINTER(ctypes.c_int), _vp, _i, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -14,7 +14,7 @@ or a device tensor (returns a device tensor: the loops use this form and never l
 import numpy as np
 import torch
 
-from . import ops
+from . import legacy_rng, ops
 
 _DEFAULT_DTYPE = torch.float32
 
@@ -146,7 +146,7 @@ class Problem():
         if size > self.M:
             print('MB size is too big: ', size, ' > ', self.M)
         batch = np.zeros(self.M)
-        batch_locs = np.random.choice(self.M, size, replace=False)
+        batch_locs = legacy_rng.choice(self.M, size)              # = np.random.choice(self.M, size, replace=False)
         batch[batch_locs] = 1
         return batch.astype(int)
 
@@ -212,7 +212,7 @@ class CSMRI(Problem):
             print('MB size is too big: ', size, ' > ', self.M)
         batch = np.zeros(self.M)
         mask_locs = np.asarray(np.flatnonzero(self.mask))
-        batch_locs = np.random.choice(mask_locs, size, replace=False)
+        batch_locs = legacy_rng.choice(mask_locs, size)           # = np.random.choice(mask_locs, size, replace=False)
         batch[batch_locs] = 1
         return batch.reshape(self.H, self.W).astype(int)
 
@@ -224,7 +224,7 @@ class CSMRI(Problem):
         locs = self.__dict__.get('_mask_locs')
         if locs is None:
             locs = self._mask_locs = np.asarray(np.flatnonzero(self.mask))
-        return np.random.choice(locs, size, replace=False)
+        return legacy_rng.choice(locs, size)
 
     def _selector(self, mb):
         """mask o mb (CSMRI.py:84) -> transposed device selector."""

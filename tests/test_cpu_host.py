@@ -252,3 +252,31 @@ def test_w44_accumulators_untouched():
                          timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert '0 problem(s)' in out.stdout
+
+
+def test_legacy_choice_matches_numpy():
+    """`legacy_rng.choice` (C restatement of np.random.choice(..., replace=False), csrc/legacy_rng.cpp) against NumPy itself:
+    the same values and dtype, and the same stream afterwards (uniform and cached-Gaussian draws that follow), for the draws the
+    reference makes (problems/CSMRI.py:72 on the sampled locations, problems/problem.py:114 on range(M)) and the corner cases;
+    both the in-place path and the get_state / set_state path."""
+    from pnp_svrg_amd import legacy_rng
+    cases = [(np.arange(3, 131073, 10), 1000), (65536, 1000), (np.arange(5), 5), (1, 1), (10, 0), (2, 1), (625, 624),
+             (np.sort(np.random.RandomState(7).choice(65536, 13107, replace=False)), 13107)]
+    for inplace in (None, False):
+        for seed in (0, 3, 2 ** 31 - 1):
+            for pool, size in cases:
+                np.random.seed(seed)
+                np.random.randn(3)                               # leaves a cached Gaussian and an odd position
+                want = [np.random.choice(pool, size, replace=False) for _ in range(3)]
+                tail_w = (np.random.rand(), np.random.randn(), np.random.get_state()[2])
+                np.random.seed(seed)
+                np.random.randn(3)
+                legacy_rng._inplace = inplace
+                got = [legacy_rng.choice(pool, size) for _ in range(3)]
+                tail_g = (np.random.rand(), np.random.randn(), np.random.get_state()[2])
+                for w, g in zip(want, got):
+                    assert w.dtype == g.dtype and np.array_equal(w, g)
+                assert tail_w == tail_g
+    legacy_rng._inplace = None
+    with pytest.raises(ValueError):
+        legacy_rng.choice(5, 6)

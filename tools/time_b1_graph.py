@@ -22,11 +22,15 @@ c = AA._Ctx(p, D.TVDenoiser(), A.CountingClock())
 t0 = time.perf_counter()
 outers = list(AA._svrg_graph_schedule(c, p, tt, 10, 1000))
 print(f'host schedule alone: {(time.perf_counter() - t0) / n * 1e6:.1f} us/inner ({len(outers)} outer iterations)', flush=True)
+torch.cuda.synchronize(); t0 = time.perf_counter()
 run = AA._SvrgGraph(p, D.TVDenoiser(), 2e3, 10, 1000, 'svrg', 8192)
+run.upload(outers)
 run.log_psnr()
-run.run_lists(outers[0]); torch.cuda.synchronize()
-t0 = time.perf_counter()
-for l in outers[1:]:
-    run.run_lists(l)
-t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-print(f'run_lists x {len(outers) - 1}: host {(t1 - t0) / (len(outers) - 1) * 1e3:.3f} ms per outer, then sync {1e3 * (t2 - t1):.2f} ms', flush=True)
+torch.cuda.synchronize(); t1 = time.perf_counter()
+run.run_outer(0, len(outers[0])); torch.cuda.synchronize(); t2 = time.perf_counter()
+for o in range(1, len(outers)):
+    run.run_outer(o, len(outers[o]))
+t3 = time.perf_counter(); torch.cuda.synchronize(); t4 = time.perf_counter()
+print(f'setup + upload {1e3 * (t1 - t0):.2f} ms; first outer iteration (capture + instantiate + replay) {1e3 * (t2 - t1):.2f} ms; '
+      f'{len(outers) - 1} replays: host {(t3 - t2) / (len(outers) - 1) * 1e3:.3f} ms per outer, device done after {1e3 * (t4 - t2):.2f} ms '
+      f'= {1e6 * (t4 - t2) / (n - 10):.1f} us per inner iteration', flush=True)

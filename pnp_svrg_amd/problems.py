@@ -211,24 +211,34 @@ class CSMRI(Problem):
         if size > self.M:
             print('MB size is too big: ', size, ' > ', self.M)
         batch = np.zeros(self.M)
-        mask_locs = np.asarray(np.flatnonzero(self.mask))
+        mask_locs = self._locs()
         batch_locs = legacy_rng.choice(mask_locs, size)           # = np.random.choice(mask_locs, size, replace=False)
         batch[batch_locs] = 1
-        return batch.reshape(self.H, self.W).astype(int)
+        mb = batch.reshape(self.H, self.W).astype(int)
+        self._last_mb = (mb, batch_locs)                          # grad_stoch(z, mb) with this very array skips its flatnonzero
+        return mb
+
+    def _locs(self):
+        """np.flatnonzero(self.mask) (CSMRI.py:71), computed once: the mask does not change after construction."""
+        locs = self.__dict__.get('_mask_locs')
+        if locs is None:
+            locs = self._mask_locs = np.asarray(np.flatnonzero(self.mask))
+        return locs
 
     def _select_mb_locs(self, size):
         """The draw of select_mb without building the H x W indicator: the same np.random.choice call on the same
         (cached) array of sampled locations, so the legacy stream advances identically."""
         if size > self.M:
             print('MB size is too big: ', size, ' > ', self.M)
-        locs = self.__dict__.get('_mask_locs')
-        if locs is None:
-            locs = self._mask_locs = np.asarray(np.flatnonzero(self.mask))
-        return legacy_rng.choice(locs, size)
+        return legacy_rng.choice(self._locs(), size)
 
     def _selector(self, mb):
         """mask o mb (CSMRI.py:84) -> transposed device selector."""
-        sel = np.flatnonzero(np.multiply(self.mask, np.asarray(mb).reshape(self.H, self.W))).astype(np.int32)
+        last = self.__dict__.get('_last_mb')
+        if last is not None and last[0] is mb and np.count_nonzero(mb) == last[1].shape[0]:
+            sel = last[1].astype(np.int32)                        # select_mb's own locations: all inside the mask, 1 each
+        else:
+            sel = np.flatnonzero(np.multiply(self.mask, np.asarray(mb).reshape(self.H, self.W))).astype(np.int32)
         idx = torch.from_numpy(sel).to(self.device).reshape(1, -1)
         return self.plan.sel_from_indices(idx, out=self._selT)
 

@@ -485,18 +485,34 @@ class GdEngine(LoopEngine):
 
 
 class _StochEngine(LoopEngine):
-    def __init__(self, batch, prox, eta, mini_batch_size, lr_decay=1.0, n_log=4096, seed=0, n_slots=1):
+    # Engines that draw one minibatch per step (sgd, saga, sarah) draw AHEAD steps per launch: the draw kernel is
+    # latency-bound (a 32-step radix select per problem, ~50 us whatever the grid), and a step's descriptor depends on
+    # (seed, step, problem) only, so a window of steps drawn together holds the very same selections.
+    AHEAD = 16
+
+    def __init__(self, batch, prox, eta, mini_batch_size, lr_decay=1.0, n_log=4096, seed=0, n_slots=None):
         super().__init__(batch, prox, eta, lr_decay, n_log, seed)
         batch._check_mb(mini_batch_size)
         self.mb = mini_batch_size
-        self.mbs = batch.minibatches(n_slots)
+        self._window = n_slots is None                          # one draw launch per AHEAD steps (else: the subclass draws)
+        self.mbs = batch.minibatches(self.AHEAD if n_slots is None else n_slots)
+        self._drawn_base = None                                 # first step of the window the slots currently hold
 
     def _minibatch(self, idx_s, step_id):
-        """Bind slot 0 to this step's minibatch: host index lists when given, else a device draw."""
-        if idx_s is None:
-            self.b.draw(self.mbs, self.mb, self.seed, step_id, 1)
-        else:
+        """Bind a slot to this step's minibatch and return it: host index lists when given (slot 0), else a device draw."""
+        if idx_s is not None:
             self.b.set_host(self.mbs, 0, idx_s)
+            self._drawn_base = None
+            return 0
+        if not self._window or step_id >= 0xFFFFFFF0:          # (0xFFFFFFFF: the table-filling draw of pnp_saga)
+            self.b.draw(self.mbs, self.mb, self.seed, step_id, 1)
+            self._drawn_base = None
+            return 0
+        base = step_id - step_id % self.AHEAD
+        if self._drawn_base != base:
+            self.b.draw(self.mbs, self.mb, self.seed, base, self.AHEAD)
+            self._drawn_base = base
+        return step_id - base
 
     def _draw_slot(self, slot, step_id):
         one = Minibatches.__new__(Minibatches)
@@ -510,9 +526,9 @@ class SgdEngine(_StochEngine):
     """pnp_sgd over a batch (algorithms/pnp_sgd.py:24-70): v = grad_stoch(z, mb) / mini_batch_size."""
 
     def step(self, idx_s=None):
-        self._minibatch(idx_s, self.s)
+        j = self._minibatch(idx_s, self.s)
         lr = self.eta * self.lr_decay ** self.s
-        self.b.grad_stoch(self.z, self.mbs, 0, out=self.z, alpha=-lr / self.mb, beta=1.0, c1=self.z)
+        self.b.grad_stoch(self.z, self.mbs, j, out=self.z, alpha=-lr / self.mb, beta=1.0, c1=self.z)
         self.z = self._prox(self.z)
         self.s += 1
 
@@ -678,8 +694,8 @@ class SarahEngine(_StochEngine):
             b.grad_full(self.z, out=self.v_prev)
             ops.axpbypcz(1.0, self.w_prev, -self.eta, self.v_prev, out=self.w_next)
             self.w_next = self._prox(self.w_next)
-        self._minibatch(idx_s, s)
-        b.grad_stoch_diff(self.w_next, self.w_prev, self.mbs, 0, out=self.v_next, alpha=1.0 / self.mb, beta=1.0, c1=self.v_prev)
+        j = self._minibatch(idx_s, s)
+        b.grad_stoch_diff(self.w_next, self.w_prev, self.mbs, j, out=self.v_next, alpha=1.0 / self.mb, beta=1.0, c1=self.v_prev)
         lr = self.eta * self.lr_decay ** (s // self.T2)
         ops.axpbypcz(1.0, self.z, -lr, self.v_next, out=self.z)
         self.z = self._prox(self.z)
@@ -701,8 +717,8 @@ class SagaEngine(_StochEngine):
         self.g = torch.empty_like(self.z)
         self._rng = np.random.default_rng(seed + 977)
         # pnp_saga.py:25-31: one minibatch gradient at Xinit fills the whole table
-        self._minibatch(idx0, 0xFFFFFFFF)
-        batch.grad_stoch(self.z, self.mbs, 0, out=self.g, alpha=1.0 / self.mb)
+        j = self._minibatch(idx0, 0xFFFFFFFF)
+        batch.grad_stoch(self.z, self.mbs, j, out=self.g, alpha=1.0 / self.mb)
         self.table = self.g.unsqueeze(0).repeat(hist_size, 1, 1, 1).contiguous()
         self.tsum = ops.axpbypcz(float(hist_size), self.g, out=torch.empty_like(self.g))
         self.r_prev = 0
@@ -711,9 +727,9 @@ class SagaEngine(_StochEngine):
         raise NotImplementedError('build a new SagaEngine (the table initialisation is part of the constructor)')
 
     def step(self, idx_s=None, r=None):
-        self._minibatch(idx_s, self.s)
+        j = self._minibatch(idx_s, self.s)
         r = int(self._rng.integers(self.hist)) if r is None else int(r)
-        self.b.grad_stoch(self.z, self.mbs, 0, out=self.g, alpha=1.0 / self.mb)
+        self.b.grad_stoch(self.z, self.mbs, j, out=self.g, alpha=1.0 / self.mb)
         lr = self.eta * self.lr_decay ** self.s
         ops.saga_table_update(self.z, self.g, self.table[r], self.table[self.r_prev], self.tsum, lr, 1.0 / self.hist)
         self.r_prev = r

@@ -229,3 +229,29 @@ def test_config5_sweep_dncnn_vs_oracle(g_csmri):
         assert abs(r['psnr_init'] - pso[0]) <= 0.01 + 1e-9
         assert np.abs(r['z'].ravel() - ro['z']).max() < 5e-4
         assert np.isfinite(r['psnr_final'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('algo', ['sgd', 'saga', 'sarah'])
+def test_draw_ahead_window_equals_single_step_draws(algo):
+    """The per-step engines draw AHEAD steps of minibatches per launch (the draw kernel is latency-bound): the same
+    iterates and logs, bit for bit, as with one draw launch per step -- over a window boundary, over both batch types,
+    and with a host-fed step in the middle of a window."""
+    from pnp_svrg_amd import engine as E
+    runs = []
+    for ahead in (16, 1, 5):
+        for mk in (lambda: E.CsmriBatch.synthetic(3, 64, 64, 0.25, 20.0, seed=8), lambda: E.DeblurBatch.synthetic(2, 64, 64, 'Minimal', 20.0, seed=2)):
+            batch = mk()
+            old = E._StochEngine.AHEAD
+            E._StochEngine.AHEAD = ahead
+            try:
+                eng = E.make_engine(batch, E.TVProx(), 5e2 if isinstance(batch, E.CsmriBatch) else 1e3, 4, 150, algorithm=algo, hist_size=5, seed=11)
+                host = batch.draw_minibatches(1, 150, seed=4)[0]
+                for s in range(21):
+                    eng.step(host) if s == 9 else eng.step()
+            finally:
+                E._StochEngine.AHEAD = old
+            runs.append((ahead, eng.z.clone(), eng.psnr_trace()))
+    for k in (0, 1):
+        for other in (2 + k, 4 + k):
+            assert torch.equal(runs[k][1], runs[other][1]) and np.array_equal(runs[k][2], runs[other][2])

@@ -73,6 +73,7 @@ def parse():
                          'split-fp16 products with fp32 accumulation (fp32-class accuracy, not the reference arithmetic): '
                          'the line then says dtype "f32 via 3 x f16 split" and prices the conv against the f16 matrix peak')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
+    ap.add_argument('--cpu-baseline-child', default=None, metavar='WORKLOAD:SECONDS', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -83,6 +84,19 @@ def _synth_image(rng):
 
 
 def cpu_baseline(workload, weights, budget_s=12.0):
+    """The CPU baseline in a child process that never touches the GPU, so that the oracle's NumPy / torch-CPU threads do not
+    share a process with the HIP runtime's.  (On the shared hosts of the GPU pool the DnCNN figure still moves between 6 and 31
+    inner-iterations/s from run to run with the placement of its 16 threads, tools/check_child_baseline.py.)  `weights` is
+    ignored here: the child loads the same fixture."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', f'{workload}:{budget_s}']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=60 + 20 * budget_s)
+    if out.returncode != 0:
+        raise RuntimeError('cpu_baseline child failed: ' + out.stderr[-2000:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def _cpu_baseline_here(workload, weights, budget_s=12.0):
     """The oracle (oracle/: NumPy + torch-CPU restatement of the reference path) on the host cores:
     the same inner iteration, one problem at a time, for ~budget_s seconds."""
     from oracle import problems as op, denoise as od
@@ -292,8 +306,21 @@ def workload_desc(workload, wdesc):
             + (f'DnCNN-17 prox ({wdesc})' if workload == 'dncnn' else 'TV (Haar BayesShrink) prox'))
 
 
+def _weights():
+    """the reference's own DnCNN sigma=15 weights (committed fixture) when present, else random init"""
+    wfile = os.path.join(ROOT, 'tests', 'golden', 'dncnn_noise15.npz')
+    if os.path.exists(wfile):
+        return dict(np.load(wfile)), 'reference DnCNN_noise15 weights'
+    from pnp_svrg_amd.denoisers import random_dncnn_weights
+    return random_dncnn_weights(17, seed=0), 'random-init weights'
+
+
 def main():
     a = parse()
+    if a.cpu_baseline_child is not None:                        # (no GPU call on this path)
+        wl, budget = a.cpu_baseline_child.split(':')
+        print(json.dumps(_cpu_baseline_here(wl, _weights()[0] if wl == 'dncnn' else None, float(budget))))
+        return
     world_env = os.environ.get('WORLD_SIZE')
     if a.gpus > 1 and world_env is None:
         # launched the documented way without torchrun: start the N ranks as children (this process has not touched
@@ -328,14 +355,10 @@ def main():
     if a.conv is not None:
         os.environ['PNP_DNCNN_WINOGRAD'] = {'f32-winograd44': '5', 'f32-winograd4': '4', 'f32-winograd': '1', 'f32-direct': '0', 'f16x3': '3'}[a.conv]
     from pnp_svrg_amd import ops
-    from pnp_svrg_amd.denoisers import random_dncnn_weights
     ops.require_gpu()
 
     B = a.batch if a.batch is not None else {'dncnn': 120, 'tv': 1024, 'saga-nlm': 64}[a.workload]
-    # the reference's own DnCNN sigma=15 weights (committed fixture) when present, else random init
-    wfile = os.path.join(ROOT, 'tests', 'golden', 'dncnn_noise15.npz')
-    weights = dict(np.load(wfile)) if os.path.exists(wfile) else random_dncnn_weights(17, seed=0)
-    wdesc = 'reference DnCNN_noise15 weights' if os.path.exists(wfile) else 'random-init weights'
+    weights, wdesc = _weights()
 
     def sync_all():
         torch.cuda.synchronize()

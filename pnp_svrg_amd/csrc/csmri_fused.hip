@@ -72,6 +72,15 @@ __device__ __forceinline__ bool in_half(int kx, int half) {
     const bool a = kx <= 63 || kx == 128 || kx >= 193;
     return half == 0 ? a : !a;
 }
+// the same for kx = l + 16 r with the row index r a compile-time constant: fourteen of the sixteen r belong to one half
+// for every lane (only kx = 128 and kx = 192, lane 0 of r = 8 and r = 12, sit on the other side), and said so the
+// compiler sees that those registers of Z are dead between the hand-over and the reload -- with a per-lane predicate
+// on every r it kept all 128 alive through both halves and spilled 80 registers around the column transforms
+__device__ __forceinline__ bool in_half_r(int r, int l, int half) {
+    if (r == 8) return (l == 0) == (half == 0);
+    if (r == 12) return (l == 0) == (half == 1);
+    return (r < 4 || r > 12) == (half == 0);
+}
 __device__ __forceinline__ int kx_local(int kx, int half) {
     if (half == 0) return kx <= 63 ? kx : (kx == 128 ? 64 : kx - 128);           // 0..63, 64, 65..127
     return kx <= 127 ? kx - 64 : kx - 65;                                        // 64..127 -> 0..63, 129..192 -> 64..127
@@ -223,7 +232,7 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kx = l + 16 * r;
-                if (in_half(kx, half)) ldc[kx_local(kx, half) * F_RS + p * FG + g] = Z[p][r];
+                if (in_half_r(r, l, half)) ldc[kx_local(kx, half) * F_RS + p * FG + g] = Z[p][r];
             }
         // this group's two column pairs and their selector bits (rows ca and W - ca of the transposed bit mask)
         ColPair cp[2];
@@ -254,7 +263,7 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kx = l + 16 * r;
-                if (in_half(kx, half)) Z[p][r] = ldc[kx_local(kx, half) * F_RS + p * FG + g];
+                if (in_half_r(r, l, half)) Z[p][r] = ldc[kx_local(kx, half) * F_RS + p * FG + g];
             }
     }
     __syncthreads();

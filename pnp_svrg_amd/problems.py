@@ -235,8 +235,9 @@ class CSMRI(Problem):
     def _selector(self, mb):
         """mask o mb (CSMRI.py:84) -> transposed device selector."""
         last = self.__dict__.get('_last_mb')
-        if last is not None and last[0] is mb and np.count_nonzero(mb) == last[1].shape[0]:
-            sel = last[1].astype(np.int32)                        # select_mb's own locations: all inside the mask, 1 each
+        if (last is not None and last[0] is mb and np.count_nonzero(mb) == last[1].shape[0]
+                and mb.reshape(-1)[last[1]].all()):             # (same count + every drawn location still set = the same set)
+            sel = last[1].astype(np.int32)                        # select_mb's own locations: all inside the mask
         else:
             sel = np.flatnonzero(np.multiply(self.mask, np.asarray(mb).reshape(self.H, self.W))).astype(np.int32)
         idx = torch.from_numpy(sel).to(self.device).reshape(1, -1)

@@ -352,3 +352,27 @@ def test_svrg_graph_replay_equals_eager_loop(api):
     dev_us = (time.perf_counter() - t0) / 500 * 1e6
     print(f'device side of the replayed loop: {dev_us:.1f} us per inner iteration (incl. 1/10 of the full-gradient refresh)')
     assert dev_us < 400      # (at B = 1 the one-workgroup-per-image kernels are bound by a single CU, not by launches)
+
+
+@pytest.mark.gpu
+def test_grad_stoch_minibatch_shortcut_is_only_taken_for_select_mbs_own_array(api):
+    """grad_stoch(z, mb) takes select_mb's index list instead of a second flatnonzero when `mb` IS the array select_mb just
+    returned (CSMRI.py:66-89 as the loops call them): the same gradient as for an equal copy of it (the general path), and
+    an array that was changed afterwards -- one entry removed, one added, or an older draw -- goes the general way too."""
+    _, problems, _ = api
+    np.random.seed(0)
+    p = problems.CSMRI(IMG64, H=64, W=64, sample_prob=0.5, snr=20., dtype=torch.float64)
+    z = np.asarray(p.Xinit) + 0.01 * np.random.RandomState(1).rand(p.N)
+    old = p.select_mb(200)
+    mb = p.select_mb(200)
+    g_short = p.grad_stoch(z, mb)
+    np.testing.assert_array_equal(g_short, p.grad_stoch(z, mb.copy()))
+    np.testing.assert_array_equal(p.grad_stoch(z, old), p.grad_stoch(z, old.copy()))
+    assert not np.array_equal(g_short, p.grad_stoch(z, old))
+    ys, xs = np.nonzero(mb)
+    mb[ys[0], xs[0]] = 0                                        # in place: same object, one entry fewer
+    np.testing.assert_array_equal(p.grad_stoch(z, mb), p.grad_stoch(z, mb.copy()))
+    assert not np.array_equal(g_short, p.grad_stoch(z, mb))
+    free = np.argwhere((p.mask != 0) & (mb == 0))[0]
+    mb[free[0], free[1]] = 1                                    # back to 200 entries, a different set
+    np.testing.assert_array_equal(p.grad_stoch(z, mb), p.grad_stoch(z, mb.copy()))

@@ -20,6 +20,8 @@ def _state_in_place():
     """(address, ok): the global RandomState's MT19937 state struct, checked once against get_state()."""
     global _inplace
     bg = np.random.mtrand._rand._bit_generator
+    if type(bg).__name__ != 'MT19937':                          # np.random.set_bit_generator(...): not the legacy stream's layout
+        return 0, False
     addr = bg.ctypes.state_address
     if _inplace is None:
         st = np.random.get_state()
@@ -51,6 +53,8 @@ def choice(pool, size):
                    work.ctypes.data, out.ctypes.data)
             return out
     st = np.random.get_state()
+    if st[0] != 'MT19937':
+        return np.random.choice(pool, size, replace=False)          # another bit generator: NumPy's own draw
     key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
     pos = ctypes.c_int(int(st[2]))
     N.call('pnp_legacy_choice', key.ctypes.data, ctypes.byref(pos), pool_ptr, pop, size, work.ctypes.data, out.ctypes.data)

@@ -90,6 +90,15 @@ class _Ctx:
     def psnr(self, v):
         return self.p.PSNR(v)
 
+    def psnr_of_current(self, z):
+        """problem.PSNR(z) at the top of an iteration of pnp_gd / sgd / saga / svrg (`start_PSNR`, e.g. pnp_svrg.py:50): in
+        those loops z is, at that point, exactly the image whose PSNR was logged last (the initial entry, or the prox
+        output of the previous iteration), so on the device path the logged value is taken instead of another error-sum
+        kernel and a blocking read-back per iteration.  (Not for pnp_sarah, whose log also holds w_next's PSNR, F6.)"""
+        if self.native and self.psnr_per_iter:
+            return self.psnr_per_iter[-1]
+        return self.psnr(z)
+
     def step(self, z, lr, v):
         """z -= lr*v (in place)."""
         if isinstance(z, torch.Tensor):
@@ -148,7 +157,7 @@ def _run_flat(c, z, eta, tt, lr_decay, converge_check, diverge_check, verbose, d
     """Body shared by pnp_gd / pnp_sgd / pnp_saga: one gradient step + one prox per pass."""
     i = 0
     while (c.clock() - elapsed) < tt:
-        start_psnr = c.psnr(z)
+        start_psnr = c.psnr_of_current(z)
         g0 = c.clock()
         v = direction(z)
         c.step(z, eta * lr_decay ** i, v)
@@ -394,7 +403,7 @@ def pnp_svrg(problem, denoiser, eta, tt, T2, mini_batch_size, verbose=True, lr_d
         for j in range(T2):
             if (c.clock() - elapsed) >= tt:
                 break
-            start_psnr = c.psnr(z)
+            start_psnr = c.psnr_of_current(z)
             g0 = c.clock()
             mb = problem.select_mb(mini_batch_size)          # drawn even when unused (RNG parity, F1)
             lr = eta * lr_decay ** i

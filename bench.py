@@ -73,6 +73,8 @@ def parse():
                          'split-fp16 products with fp32 accumulation (fp32-class accuracy, not the reference arithmetic): '
                          'the line then says dtype "f32 via 3 x f16 split" and prices the conv against the f16 matrix peak')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
+    ap.add_argument('--no-fold', action='store_true', help='A/B: the outer full-gradient refresh as launches of its own instead of '
+                                                            'folded into the first inner iteration (one-kernel iteration only)')
     ap.add_argument('--cpu-baseline-child', default=None, metavar='WORKLOAD:SECONDS', help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -181,7 +183,8 @@ class Workload:
         else:
             self.batch = CsmriBatch.synthetic(B, H, W, SAMPLE_PROB, SNR, seed=100 + rank)
             self.prox = DnCNNProx(weights, NET_SIGMA) if name == 'dncnn' else TVProx()
-            self.eng = make_engine(self.batch, self.prox, ETA, T2, MB, variant='svrg', seed=1 + rank)
+            self.eng = make_engine(self.batch, self.prox, ETA, T2, MB, variant='svrg', seed=1 + rank,
+                                   fold_outer=not getattr(a, 'no_fold', False))
             self.mbsize = MB
         self.n_draw = 0
         self.idx = None

@@ -114,6 +114,21 @@ int pnp_csmri_svrg_step(pnp_csmri_plan* plan, const void* a, const void* b, cons
                         int denoise, double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out,
                         void* sigma_out, void* stream);
 
+/* The outer-loop refresh of the SVRG loop -- algorithms/pnp_svrg.py:32-38: mu = grad_full(z); w = copy(z) -- folded into the first
+ * inner iteration of that outer iteration (:52-80 at j = 0).  There w == z, so the minibatch difference
+ * grad_stoch(z, mb) - grad_stoch(w, mb) is exactly zero whatever the minibatch and the iteration is z <- prox(z - lr * mu):
+ *     mu_out = alpha_vec[b] * Re ifft2( mask o fft2(z) - Y on the mask )         (= problems/CSMRI.py:76-81, yh packed by
+ *                                                                                  pnp_csmri_pack_y for mask_bitsT's mask)
+ *     w_out  = z
+ *     out    = prox_TV( z + (-lr) * mu_out )              [+ noise estimate, PSNR error: as pnp_csmri_svrg_step]
+ * in ONE kernel -- bit for bit what pnp_csmri_grad_sel (bits form, batch >= 192) + a copy + pnp_csmri_svrg_step(a = z,
+ * b = w, c1 = z, c2 = mu, beta = 1, gamma = -lr) produce, without the second transform pair and the copy.  w_out and mu_out
+ * must not alias z, out or each other; out may alias z.                                                      */
+int pnp_csmri_svrg_outer_step(pnp_csmri_plan* plan, const void* z, const uint32_t* mask_bitsT, const void* yh,
+                              const void* alpha_vec, double lr, void* w_out, void* mu_out, void* out, int denoise,
+                              double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out,
+                              void* sigma_out, void* stream);
+
 /* ------------------------------------------------------------------ Deblur / super-resolution
  * Replaces problems/DeblurSR.py:119-147: 1-D circular blur of the raveled image via a length-H*W FFT
  * (spectrum of the kernel computed once at plan creation), optional 4-tap bilinear down-sampler

@@ -24,8 +24,14 @@ template <typename T> struct cx { T x, y; };
 
 template <typename T> __device__ __forceinline__ cx<T> cadd(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename T> __device__ __forceinline__ cx<T> csub(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+// Complex product with the fused multiply-adds SPELLED OUT: under the compiler's default contraction, which of the two
+// products of `a.x * b.x - a.y * b.y` gets fused is decided per call site, so two instantiations of the same transform could
+// differ in the last bit (seen between the gradient-only and the whole-iteration forms of k_svrg_iter); written this way
+// every kernel rounds the same way.
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
-    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    return {fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)};
 }
 template <typename T> __device__ __forceinline__ cx<T> cconj(cx<T> a) { return {a.x, -a.y}; }
 

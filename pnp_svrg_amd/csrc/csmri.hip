@@ -435,7 +435,7 @@ namespace pnp {
 int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* b, const uint32_t* bitsT, const void* yh,
                        double alpha, const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
                        int mode, double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
-                       void* stream);
+                       void* stream, void* w_out = nullptr, void* mu_out = nullptr);
 }
 
 namespace {
@@ -504,4 +504,17 @@ extern "C" int pnp_csmri_svrg_step(pnp_csmri_plan* p, const void* a, const void*
     PNP_CHECK_ARG(!(sse_out && !xrec), "sse_out needs xrec");
     return csmri_fused_launch(p->batch, p->twtab, a, b, bitsT, nullptr, alpha, alpha_vec, beta, c1, gamma, c2, out, denoise ? 0 : 1,
                               sigma_modifier, fallback_sigma, xrec, sse_out, sigma_out, stream);
+}
+
+// ---- the same with the outer-loop refresh folded in (first inner iteration of an outer iteration)
+extern "C" int pnp_csmri_svrg_outer_step(pnp_csmri_plan* p, const void* z, const uint32_t* mask_bitsT, const void* yh,
+                                         const void* alpha_vec, double lr, void* w_out, void* mu_out, void* out, int denoise,
+                                         double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out,
+                                         void* sigma_out, void* stream) {
+    PNP_CHECK_ARG(p && z && mask_bitsT && yh && w_out && mu_out && out, "null argument");
+    PNP_CHECK_ARG(p->dtype == PNP_F32 && p->H == 256 && p->W == 256, "the one-kernel iteration exists for f32 plans of 256 x 256");
+    PNP_CHECK_ARG(!(sse_out && !xrec), "sse_out needs xrec");
+    PNP_CHECK_ARG(w_out != z && mu_out != z && w_out != mu_out && w_out != out && mu_out != out, "w_out and mu_out must be buffers of their own");
+    return csmri_fused_launch(p->batch, p->twtab, z, nullptr, mask_bitsT, yh, 1.0, alpha_vec, 1.0, z, -lr, nullptr, out,
+                              denoise ? 0 : 1, sigma_modifier, fallback_sigma, xrec, sse_out, sigma_out, stream, w_out, mu_out);
 }

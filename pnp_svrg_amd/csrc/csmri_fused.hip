@@ -128,7 +128,7 @@ __device__ __forceinline__ void col_transform(cx<float> (&v)[16], const cx<float
             const cx<float> A = {0.5f * (pk.x + pm.x), 0.5f * (pk.y - pm.y)};
             const cx<float> B = {0.5f * (pk.y + pm.y), -0.5f * (pk.x - pm.x)};
             const float wA = 0.5f * (bit(0, ky) + bit(0, km)), wB = 0.5f * (bit(1, ky) + bit(1, km));
-            v[r] = {wA * A.x - wB * B.y, wA * A.y + wB * B.x};
+            v[r] = {fma_(wA, A.x, -(wB * B.y)), fma_(wA, A.y, wB * B.x)};
         }
         __builtin_amdgcn_wave_barrier();
     } else {
@@ -165,11 +165,15 @@ __device__ __forceinline__ void col_store(const cx<float> (&v)[16], cx<float>* l
 // a, b, c1, c2: THIS image's arrays (wave-uniform pointers -> scalar base + 32-bit lane offset addressing; 64-bit per-lane
 // addresses for five arrays would cost dozens of registers).  No __restrict__ on them: the batches below are ordered by
 // memory clobbers, which the compiler may ignore for loads it knows to be invariant.
-template <int STOP = 0>
+// OUTER (the outer-loop refresh folded into the first inner iteration, algorithms/pnp_svrg.py:32-57 at j = 0): the
+// scaled transform IS mu = grad_full(z); the epilogue stores it, stores w = z (the operand c1 it has to load anyway) and
+// leaves z + gamma * mu in Z -- what the plain form computes from an all-zero difference z - w plus mu, bit for bit.
+template <int STOP = 0, bool OUTER = false>
 __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const float* a, const float* b,
                                                const uint32_t* __restrict__ bits, const cx<float>* __restrict__ twtab, cx<float>* twl, cx<float>* ldc,
                                                uint32_t (*sbits)[FG][2][16], const cx<float>* __restrict__ yh, float scale, float beta,
-                                               const float* c1, float gamma, const float* c2, int g, int l) {
+                                               const float* c1, float gamma, const float* c2, int g, int l,
+                                               float* w_out = nullptr, float* mu_out = nullptr) {
     cx<float>* scr = ldc + g * F_SCR;
     // selector bits of this group's four column pairs (two per half): fetched now, under the operand loads of phase 1 --
     // inside phase 2 their round trip to L2 sat exposed between two workgroup barriers, once per half
@@ -280,6 +284,33 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
     for (int p = 0; p < FP; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Z[p][r] = {scale * Z[p][r].x, scale * Z[p][r].y};
+    if (OUTER) {
+#pragma unroll
+        for (int p0 = 0; p0 < FP; p0 += 2) {
+            cx<float> u[2][16];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[k][r] = {c1[off[p0 + k] + 16 * r], c1[off[p0 + k] + FN + 16 * r]};
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    mu_out[off[p0 + k] + 16 * r] = Z[p0 + k][r].x;
+                    mu_out[off[p0 + k] + FN + 16 * r] = Z[p0 + k][r].y;
+                }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    w_out[off[p0 + k] + 16 * r] = u[k][r].x;
+                    w_out[off[p0 + k] + FN + 16 * r] = u[k][r].y;
+                    Z[p0 + k][r] = {u[k][r].x + gamma * Z[p0 + k][r].x, u[k][r].y + gamma * Z[p0 + k][r].y};
+                }
+            asm volatile("" ::: "memory");
+        }
+        return;
+    }
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         const float* src = which == 0 ? c1 : c2;
@@ -317,14 +348,15 @@ namespace pnp {
 // STOP (diagnostic builds, PNP_FUSED_STOP): leave after phase STOP (10 = after the operand loads of phase 1) with a checksum
 // store, to time the phases one by one
 enum { FUSED_FULL = 0, FUSED_NO_DENOISE = 1, FUSED_GRAD = 2 };
-template <int MODE, int STOP>
+template <int MODE, int STOP, bool OUTER = false>
 __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b,
                                                   const uint32_t* __restrict__ bitsT, const cx<float>* __restrict__ yh,
                                                   const cx<float>* __restrict__ twtab,
                                                   float scale, const float* __restrict__ alpha_vec, float beta, const float* c1,
                                                   float gamma, const float* c2, float* out,
                                                   float sigma_modifier, float fallback_sigma, const float* __restrict__ xrec,
-                                                  double* __restrict__ sse_out, float* __restrict__ sigma_out) {
+                                                  double* __restrict__ sse_out, float* __restrict__ sigma_out,
+                                                  float* w_out, float* mu_out) {
     constexpr bool DENOISE = MODE == FUSED_FULL;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     cx<float>* ldc = reinterpret_cast<cx<float>*>(lds_raw);
@@ -340,9 +372,10 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     if (alpha_vec != nullptr) scale *= alpha_vec[prob];
 
     cx<float> Z[FP][16];
-    fused_gradient<(STOP == 1 || STOP == 2 || STOP == 10) ? STOP : 0>(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
+    fused_gradient<(STOP == 1 || STOP == 2 || STOP == 10) ? STOP : 0, OUTER>(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
                    yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
-                   c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l);
+                   c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l,
+                   OUTER ? w_out + img : nullptr, OUTER ? mu_out + img : nullptr);
     if (MODE == FUSED_GRAD) {
         float* oi = out + img;
 #pragma unroll
@@ -468,7 +501,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
 int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* b, const uint32_t* bitsT, const void* yh,
                        double alpha, const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
                        int mode, double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
-                       void* stream) {
+                       void* stream, void* w_out, void* mu_out) {
     const float scale = (float)(alpha / ((double)FN * (double)FN));
     hipStream_t s = (hipStream_t)stream;
     const char* stop_env = getenv("PNP_FUSED_STOP");
@@ -486,15 +519,20 @@ int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* 
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
         PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
         attr_done |= 1ull << (dev & 63);
     }
-#define PNP_FUSED_LAUNCH(MD, ST)                                                                                          \
-    k_svrg_iter<MD, ST><<<batch, FT, F_LDS_BYTES, s>>>((const float*)a, (const float*)b, bitsT, (const cx<float>*)yh,          \
+#define PNP_FUSED_LAUNCH(MD, ST, ...)                                                                                     \
+    k_svrg_iter<MD, ST, ##__VA_ARGS__><<<batch, FT, F_LDS_BYTES, s>>>((const float*)a, (const float*)b, bitsT, (const cx<float>*)yh, \
                                                        (const cx<float>*)twtab, scale, (const float*)alpha_vec, (float)beta,    \
                                                        (const float*)c1, (float)gamma, (const float*)c2, (float*)out,         \
                                                        (float)sigma_modifier, (float)fallback_sigma, (const float*)xrec,      \
-                                                       sse_out, (float*)sigma_out)
-    if (mode == FUSED_GRAD) PNP_FUSED_LAUNCH(2, 0);
+                                                       sse_out, (float*)sigma_out, (float*)w_out, (float*)mu_out)
+    if (w_out != nullptr) {                                     // the outer refresh folded into the first inner iteration
+        if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0, 0, true);
+        else PNP_FUSED_LAUNCH(1, 0, true);
+    } else if (mode == FUSED_GRAD) PNP_FUSED_LAUNCH(2, 0);
     else if (stop == 1) PNP_FUSED_LAUNCH(0, 1);
     else if (stop == 2) PNP_FUSED_LAUNCH(0, 2);
     else if (stop == 10) PNP_FUSED_LAUNCH(0, 10);

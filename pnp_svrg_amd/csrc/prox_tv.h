@@ -52,6 +52,33 @@ template <typename K> __device__ __forceinline__ K col_min(K v) {
     return v;
 }
 
+// In-register transpose of a 32 x 32 bit matrix: on return bit i of a[b] is what bit b of a[i] was.  Five butterfly
+// stages (J = 16, 8, 4, 2, 1): rows k and k + J trade the low row's high part for the high row's low part.
+template <int J> __device__ __forceinline__ void transpose32_stage(uint32_t (&a)[32]) {
+    constexpr uint32_t m = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu : J == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (k & J) continue;
+        const uint32_t lo = a[k], hi = a[k + J];
+        a[k] = (lo & m) | ((hi & m) << J);
+        a[k + J] = ((lo >> J) & m) | (hi & ~m);
+    }
+}
+__device__ __forceinline__ void transpose32(uint32_t (&a)[32]) {
+    transpose32_stage<16>(a);
+    transpose32_stage<8>(a);
+    transpose32_stage<4>(a);
+    transpose32_stage<2>(a);
+    transpose32_stage<1>(a);
+}
+
+template <int N> struct IntC { static constexpr int value = N; };
+// f(IntC<BIT>{}) for BIT = FROM, FROM - 1, ..., 0
+template <int FROM, typename F> __device__ __forceinline__ void radix_bits(F&& f) {
+    f(IntC<FROM>{});
+    if constexpr (FROM > 0) radix_bits<FROM - 1>(f);
+}
+
 // MAD sigma of one column from this lane's chunk x[0..RPC) (all 4 lanes of the column get it).
 template <typename T, int RPC>
 __device__ __forceinline__ T column_sigma(const T (&x)[RPC], int q) {
@@ -84,14 +111,42 @@ __device__ __forceinline__ T column_sigma(const T (&x)[RPC], int q) {
     // k-th smallest by bitwise radix select over the (monotone) bit patterns of |d|
     const int k = (n - 1) >> 1;
     K pfx = 0;
-#pragma unroll 1
-    for (int bit = KeyOf<T>::BITS - 1; bit >= 0; --bit) {
-        const K cand = pfx | ((K)1 << bit);
-        int c = 0;
+    if constexpr (sizeof(T) == 4 && NC == 33) {
+        // Bit-sliced form (H = 256, f32): keys 0..31 are transposed into 32 bit planes (plane b, bit i = bit b of key i:
+        // a 32 x 32 bit-matrix transpose in registers, five butterfly stages), after which one radix step is a mask, a
+        // population count and the column reduction -- ~20 vector instructions per bit instead of two per key and bit
+        // (66 + reduction).  The 33rd key (the bottom chunk's extra coefficient) rides along as a flag.  Same result:
+        // the (k+1)-th smallest key; masked keys (all ones) are never below a candidate.
+        uint32_t pl[32];
 #pragma unroll
-        for (int i = 0; i < NC; ++i) c += key[i] < cand ? 1 : 0;
-        c = col_sum(c);
-        if (c <= k) pfx = cand;
+        for (int i = 0; i < 32; ++i) pl[i] = key[i];
+        transpose32(pl);
+        const uint32_t k32 = key[32];
+        uint32_t alive = 0xFFFFFFFFu, alive32 = 1u;
+        int kk = k;
+        // (unrolled by recursion: planes are registers, so the bit index must be a compile-time constant; clang declines
+        // `#pragma unroll` on this loop because of the convergent cross-lane reductions in its body)
+        radix_bits<30>([&](auto BIT) {
+            constexpr int bit = decltype(BIT)::value;
+            const uint32_t zeros = alive & ~pl[bit];
+            const uint32_t b32 = (k32 >> bit) & 1u, z32 = alive32 & (b32 ^ 1u);
+            const int c = col_sum((int)(__builtin_popcount(zeros) + z32));     // alive keys of the column with this bit clear
+            const bool lower = kk < c;                                       // the wanted key is among them
+            alive = lower ? zeros : (alive & pl[bit]);
+            alive32 = lower ? z32 : (alive32 & b32);
+            kk = lower ? kk : kk - c;
+            pfx |= lower ? 0u : (1u << bit);
+        });
+    } else {
+#pragma unroll 1
+        for (int bit = KeyOf<T>::BITS - 1; bit >= 0; --bit) {
+            const K cand = pfx | ((K)1 << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) c += key[i] < cand ? 1 : 0;
+            c = col_sum(c);
+            if (c <= k) pfx = cand;
+        }
     }
     T med = from_key(pfx);
     if ((n & 1) == 0) {                                // even count: mean of the two middle values

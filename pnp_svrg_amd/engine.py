@@ -540,7 +540,8 @@ class SvrgEngine(_StochEngine):
     refresh (T2 descriptor slots)."""
     FUSED_MIN_BATCH = 192
 
-    def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096, seed=0, fused=None):
+    def __init__(self, batch, prox, eta, T2, mini_batch_size, lr_decay=1.0, variant='svrg', n_log=4096, seed=0, fused=None,
+                 fold_outer=True):
         super().__init__(batch, prox, eta, mini_batch_size, lr_decay, n_log, seed, n_slots=T2)
         self.T2, self.variant = T2, variant
         # the one-kernel inner iteration (csrc/csmri_fused.hip): CSMRI, f32, 256 x 256, true SVRG direction, a prox that
@@ -552,6 +553,7 @@ class SvrgEngine(_StochEngine):
         # one workgroup per image: it pays off from about a workgroup per CU (measured: B = 120 is slower than the
         # streaming kernels, B = 256 faster), so small batches keep the four streaming kernels unless asked otherwise
         self.fused = (ok and batch.B >= self.FUSED_MIN_BATCH) if fused is None else bool(fused)
+        self.fold_outer = fold_outer                            # False: refresh as launches of its own (A/B, tests)
         self._hostbits = None
         dev = batch.xrec.device
         self.w = torch.empty_like(self.z)
@@ -572,12 +574,21 @@ class SvrgEngine(_StochEngine):
         NumPy's legacy stream for reference-identical runs); None = device draws."""
         b, s = self.b, self.s
         j = s % self.T2
+        lr = self.eta * self.lr_decay ** (s // self.T2)
         if j == 0:                                              # outer: mu = grad_full(z); w = z
-            b.grad_full(self.z, out=self.mu)
-            self.w.copy_(self.z)
             if self.variant == 'svrg' and idx_s is None:
                 b.draw(self.mbs, self.mb, self.seed, s, self.T2)
-        lr = self.eta * self.lr_decay ** (s // self.T2)
+            if self.fused and self.fold_outer:
+                # ... folded into the first inner iteration: at j = 0 the SVRG difference gs(z) - gs(w) is exactly zero
+                # (w == z), so that iteration is z <- prox(z - lr * mu); ONE kernel forms mu, stores it and w, and goes on
+                if idx_s is not None:                           # (the minibatch of this step is drawn but cannot matter)
+                    b.set_host(self.mbs, j, idx_s)
+                self._fused_outer(lr, self.sse_log[self.n_prox % self.n_log])
+                self.n_prox += 1
+                self.s += 1
+                return
+            b.grad_full(self.z, out=self.mu)
+            self.w.copy_(self.z)
         if self.variant == 'svrg':
             if idx_s is not None:
                 b.set_host(self.mbs, j, idx_s)
@@ -595,6 +606,13 @@ class SvrgEngine(_StochEngine):
         self.z = self._prox(self.z)
         self.s += 1                                             # eager steps keep the index on the host (no counter launch)
 
+    def _fused_outer(self, lr, sse_out):
+        """outer refresh (mu = grad_full(z), w = z) + inner iteration 0 in one kernel (pnp_csmri_svrg_outer_step)."""
+        b, px = self.b, self.prox
+        b.plan.svrg_outer_step(self.z, b.bits, b.yh_full, b.inv_m0, lr, self.w, self.mu, out=self.z, denoise=px.fused_denoise,
+                               xrec=b.xrec, sse=sse_out if px.fused_denoise else None, **px.fused_args())
+        px.after_fused(self.z, b.xrec, sse_out)
+
     def _fused_inner(self, j, lr, sse_out):
         """step + estimate_sigma + prox + error of inner iteration j in one kernel (TV), or in one kernel + the network."""
         b, px = self.b, self.prox
@@ -610,13 +628,17 @@ class SvrgEngine(_StochEngine):
     # ---- hipGraph form: one OUTER iteration (full-gradient refresh + T2 inner iterations) = one graph launch
     def _outer_body(self):
         b = self.b
-        b.grad_full(self.z, out=self.mu)
-        self.w.copy_(self.z)
+        fold = self.variant == 'svrg' and self.fused and self.fold_outer
+        if not fold:
+            b.grad_full(self.z, out=self.mu)
+            self.w.copy_(self.z)
         lr = self.eta
         if self.variant == 'svrg':
             b.draw(self.mbs, self.mb, self.seed, 0, self.T2, step_dev=self.step_dev)
         for j in range(self.T2):
-            if self.variant == 'svrg' and self.fused:
+            if fold and j == 0:
+                self._fused_outer(lr, self.sse_tmp)
+            elif self.variant == 'svrg' and self.fused:
                 self._fused_inner(j, lr, self.sse_tmp)
             else:
                 if self.variant == 'svrg':

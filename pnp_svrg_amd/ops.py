@@ -135,6 +135,21 @@ class CsmriPlan:
         return out, sse, sigma_out
 
 
+    def svrg_outer_step(self, z, mask_bits, yh, alpha_vec, lr, w_out, mu_out, out=None, *, denoise=True, sigma_modifier=1.0,
+                        fallback_sigma=0.0, xrec=None, sse=None, sigma_out=None):
+        """pnp_csmri_svrg_outer_step: the outer refresh of pnp_svrg folded into its first inner iteration, one kernel:
+        mu_out = alpha_vec[b] * Re ifft2(mask o fft2(z) - yh), w_out = z, out = prox_TV(z - lr * mu_out)."""
+        assert self.dtype == torch.float32 and self.H == 256 and self.W == 256
+        assert mask_bits.dtype == torch.int32 and tuple(mask_bits.shape) == (self.B, self.W, self.H // 32)
+        for t in (z, w_out, mu_out, out):
+            assert t is None or (t.dtype == self.dtype and t.numel() == self.B * self.H * self.W)
+        out = out if out is not None else torch.empty_like(z)
+        sigma_out = sigma_out if sigma_out is not None else torch.empty(self.B, dtype=z.dtype, device=z.device)
+        N.call('pnp_csmri_svrg_outer_step', self._h, _p(z), _p(mask_bits), _p(yh), _p(alpha_vec), float(lr), _p(w_out), _p(mu_out),
+               _p(out), 1 if denoise else 0, float(sigma_modifier), float(fallback_sigma), _p(xrec), _p(sse), _p(sigma_out), _stream())
+        return out, sse, sigma_out
+
+
 class DncnnPlan:
     """pnp_dncnn_plan_*: DnCNN-17 prox for B images of H x W (fp32 network on the f32 matrix cores).
 

@@ -7,7 +7,7 @@ noise from the global legacy `np.random` stream, forward model) is one-off setup
 in NumPy float64 so that a seed reproduces the reference's data bit for bit.
 
 Extensions (keyword-only, all optional): `img=` (pixel array instead of a path),
-`dtype=` (torch.float32 production / torch.float64 parity), `device=`.
+`dtype=` (torch.float32 production / torch.float64 parity), `device=` (default: the current HIP device).
 Gradient methods accept either a NumPy vector (returns NumPy float64, like the reference)
 or a device tensor (returns a device tensor: the loops use this form and never leave HBM).
 """
@@ -33,7 +33,7 @@ def get_default_dtype():
 class Problem():
     """reference problems/problem.py:8-129."""
 
-    def __init__(self, img_path, H, W, *, img=None, dtype=None, device='cuda:0', upload=True):
+    def __init__(self, img_path, H, W, *, img=None, dtype=None, device=None, upload=True):
         self.H = H
         self.W = W
         self.N = H * W
@@ -51,6 +51,10 @@ class Problem():
         self.Xinit = np.empty_like(self.X)
         # device side (upload=False: host-side construction only -- the batched engines upload whole batches)
         self.dtype = dtype if dtype is not None else _DEFAULT_DTYPE
+        if device is None:
+            # the CURRENT device: one process per GPU under torchrun has set it to its LOCAL_RANK, so a problem built on
+            # rank r lives on GPU r (a fixed 'cuda:0' default made every rank but 0 raise below)
+            device = torch.device('cuda', torch.cuda.current_device()) if (upload and torch.cuda.is_available()) else torch.device('cuda')
         self.device = torch.device(device)
         self._upload_enabled = upload
         if upload:

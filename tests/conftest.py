@@ -38,6 +38,11 @@ def g_traces256():
 
 
 @pytest.fixture(scope='session')
+def g_traces256_full():
+    return golden('traces256_full.npz')
+
+
+@pytest.fixture(scope='session')
 def g_deblur():
     return golden('deblur.npz')
 

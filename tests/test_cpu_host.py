@@ -280,3 +280,20 @@ def test_legacy_choice_matches_numpy():
     legacy_rng._inplace = None
     with pytest.raises(ValueError):
         legacy_rng.choice(5, 6)
+
+
+def test_problem_default_device_is_current_device(monkeypatch):
+    """One process per GPU: a drop-in problem built on rank r must land on the CURRENT device (torchrun ranks call
+    torch.cuda.set_device(LOCAL_RANK)), not on a fixed cuda:0 -- checked with the current device mocked to 1."""
+    import pnp_svrg_amd.problems as P
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 1)
+    monkeypatch.setattr(P.ops, 'require_gpu', lambda: None)
+    monkeypatch.setattr(P.Problem, 'to_device', lambda self, a: torch.zeros(self.H * self.W))
+    img = np.arange(64.0).reshape(8, 8)
+    p = P.Problem(None, 8, 8, img=img)
+    assert p.device == torch.device('cuda', 1)
+    assert P.Problem(None, 8, 8, img=img, device='cuda:1').device == torch.device('cuda', 1)
+    with pytest.raises(Exception, match='not the current device'):
+        P.Problem(None, 8, 8, img=img, device='cuda:0')
+    assert P.Problem(None, 8, 8, img=img, upload=False).device.type == 'cuda'      # host-only construction: no device touched

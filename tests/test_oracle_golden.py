@@ -159,6 +159,19 @@ def test_traces256(g_traces256):
         np.testing.assert_allclose(r['z'], g[f'{key}_z'], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize('variant,key', [('reference', 'svrg'), ('svrg', 'truesvrg')])
+def test_traces256_full_length(g_traces256_full, variant, key):
+    """SURVEY 8(d) at its full length -- 20 outer x 10 inner iterations, eta 2e3, mb 1000, TV prox -- against the trace the
+    real reference produced (tests/golden/make_golden_r3.py): the oracle that the GPU tests of the same length lean on."""
+    g = g_traces256_full
+    p = csmri(IMG256, 256)
+    np.random.seed(1)
+    r = ol.pnp_svrg(p, od.TVDenoiser(), 2e3, 2 + 20 * 53 - (1 if variant == 'svrg' else 0), 10, 1000,
+                    converge_check=False, clock=ol.CountingClock(), variant=variant)
+    assert len(r['psnr_per_iter']) == 221 and list(r['psnr_per_iter']) == list(g[f'{key}_psnr'])
+    np.testing.assert_allclose(r['z'], g[f'{key}_z'], rtol=0, atol=1e-11)
+
+
 def test_deblur(g_deblur):
     g = g_deblur
     np.random.seed(0)

@@ -61,7 +61,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=None,
                     help='independent reconstructions per GPU (default: 120 = one Set12 x 10 sampling-ratio sweep for dncnn, '
                          '1024 for tv (SURVEY 8d batch list), 64 for saga-nlm)')
-    ap.add_argument('--workload', default='dncnn', choices=['dncnn', 'tv', 'saga-nlm'])
+    ap.add_argument('--workload', default='dncnn', choices=['dncnn', 'tv', 'saga-nlm', 'sweep'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the config-2 / config-4 secondary measurements')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -277,6 +277,43 @@ class Workload:
         self.saga_ms = e[2].elapsed_time(e[3]) / reps
 
 
+SWEEP_IMAGES, SWEEP_ALPHAS = 12, [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]
+
+
+class SweepWorkload:
+    """BASELINE config 5: Set12-shaped batch x sampling-ratio sweep (12 images x 10 ratios = 120 independent work items, reference
+    script_diff_sampratio_set12.py:113-146), DnCNN prox, pnp_svrg, dealt round-robin over the ranks by `sweep.shard` (STRONG
+    scaling: the 120 items are the whole job whatever N), every rank's items one mixed-ratio batch on the engine, and ONE
+    collective: the final gather of the reconstructions and PSNRs -- inside the timed region."""
+
+    def __init__(self, rank, world, weights, n_images=SWEEP_IMAGES, alphas=SWEEP_ALPHAS):
+        from pnp_svrg_amd import sweep
+        from pnp_svrg_amd.engine import DnCNNProx
+        self.sweep, self.name = sweep, 'sweep'
+        rng = np.random.default_rng(2024)
+        imgs = [_synth_image(rng) for _ in range(n_images)]
+        self.items = sweep.make_items(n_images, alphas, [SNR])
+        self.runner = sweep.make_runner(imgs, 'csmri', 'svrg', lambda: DnCNNProx(weights, NET_SIGMA), eta=ETA, n_inner=T2,
+                                        mini_batch_size=MB, T2=T2, H=H, W=W, seeding='generator', max_batch=128)
+        self.mine = sweep.shard(self.items, rank, world)
+        self.state = self.runner.prepare(self.mine)              # problem data resident in HBM, engines built
+        self.B = len(self.mine)
+
+    def run(self, n):
+        self.runner.advance(self.state, n)
+
+    def gather(self):
+        """the final gather (z and PSNRs of every item to rank 0): RCCL when the process group is NCCL"""
+        zs, meta = [], []
+        for c in self.state:
+            tr = c.eng.sse_log[(c.eng.n_prox - 1) % c.eng.n_log]         # squared errors of the last iteration, on the device
+            zs.append(c.eng.z)
+            meta.append(torch.stack([torch.tensor([it['id'] for it in c.items], dtype=torch.float64, device=tr.device), tr], 1))
+        z = torch.cat(zs) if zs else torch.zeros((0, H, W), dtype=torch.float32, device='cuda')
+        m = torch.cat(meta) if meta else torch.zeros((0, 2), dtype=torch.float64, device='cuda')
+        return self.sweep.gather_device(z, m, len(self.items))
+
+
 def measure(w, steps, warmup, sync_all, graph=False):
     """warmup untimed steps, then exactly `steps` timed ones bracketed by sync (+ barrier); returns seconds."""
     if graph:
@@ -296,9 +333,52 @@ def measure(w, steps, warmup, sync_all, graph=False):
     return time.perf_counter() - t0
 
 
+def run_sweep_bench(rank, world, weights, steps, warmup, sync_all, dist, cdev):
+    """Time config 5: `steps` inner iterations of all 120 items + the final gather.  Returns (seconds (max over ranks), warmup
+    steps actually run, the workload, gathered (z, meta) on rank 0)."""
+    w = SweepWorkload(rank, world, weights)
+    if steps % T2 == 0:
+        warmup = -(-max(warmup, 1) // T2) * T2                 # whole outer iterations: the timed ones then replay as hipGraphs
+    w.run(warmup)
+    w.gather()                                                  # (communicator / buffers warm)
+    sync_all()
+    t0 = time.perf_counter()
+    w.run(steps)
+    got = w.gather()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, warmup, w, got
+
+
+def sweep_fields(dt, steps, w, got, world):
+    """value / config / roofline of a sweep measurement (rank 0)."""
+    n_items = len(w.items)
+    z, meta = got
+    psnr = 10 * np.log10(1.0 / (meta[:, 1].numpy() / (H * W)))
+    flops = FLOP_MID_PER_IMAGE * 15 * n_items / WINOGRAD_REDUCTION['5']     # executed by the 15 middle layers per step, whole job
+    ex = flops * steps / dt / 1e12 / world                                   # per GPU
+    return {'value': round(n_items * steps / dt, 2), 'unit': 'item-inner-iters/s', 'ms_per_step': round(dt / steps * 1e3, 4),
+            'scaling': 'strong',
+            'config': {'workload': f'{SWEEP_IMAGES} images x {len(SWEEP_ALPHAS)} sampling ratios = {n_items} work items (reference '
+                                   f'script_diff_sampratio_set12.py), {H}x{W} CSMRI Bernoulli masks, pnp_svrg (true SVRG direction, T2={T2}, '
+                                   f'mb={MB}), DnCNN-17 prox; items dealt round-robin over ranks, each rank ONE mixed-ratio batch; final gather of '
+                                   'z and PSNR to rank 0 INSIDE the timed region',
+                       'items_total': n_items, 'items_per_gpu': -(-n_items // world),
+                       'parallelism': f'items sharded x{world}; one gather (RCCL) at the end'},
+            'roofline': {'bound': 'mfma', 'kernel': 'whole step (gradient kernels, 17-layer network, gather) priced as the F(4x4,3x3) conv layers\' executed FLOPs',
+                         'achieved': round(ex, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ex / F32_MFMA_PEAK_TFLOPS, 4),
+                         'traffic': None, 'note': 'per GPU; includes everything in the timed region, so it is a lower bound of the conv kernel\'s own fraction'},
+            'psnr_db': {'after_timed_steps_mean': float(np.mean(psnr)), 'items_gathered': int(z.shape[0])}}
+
+
 def metric_name(workload):
     return {'dncnn': 'PnP-SVRG inner-iters/sec, 256x256 CSMRI+DnCNN', 'tv': 'PnP-SVRG inner-iters/sec, 256x256 CSMRI+TV',
-            'saga-nlm': 'PnP-SAGA iters/sec, 256x256 Deblur+NLM'}[workload]
+            'saga-nlm': 'PnP-SAGA iters/sec, 256x256 Deblur+NLM',
+            'sweep': 'PnP-SVRG item-inner-iters/sec, Set12-shaped batch x 10 sampling ratios, 256x256 CSMRI+DnCNN (strong scaling)'}[workload]
 
 
 def workload_desc(workload, wdesc):
@@ -360,7 +440,7 @@ def main():
     from pnp_svrg_amd import ops
     ops.require_gpu()
 
-    B = a.batch if a.batch is not None else {'dncnn': 120, 'tv': 1024, 'saga-nlm': 64}[a.workload]
+    B = a.batch if a.batch is not None else {'dncnn': 120, 'tv': 1024, 'saga-nlm': 64, 'sweep': 120}[a.workload]
     weights, wdesc = _weights()
 
     def sync_all():
@@ -368,6 +448,21 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    cdev = 'cuda' if (dist is None or a.backend == 'nccl') else 'cpu'      # where collective buffers live
+    if a.workload == 'sweep':
+        dt, warm, w, got = run_sweep_bench(rank, world, weights, a.steps, a.warmup, sync_all, dist, cdev)
+        if rank == 0:
+            f = sweep_fields(dt, a.steps, w, got, world)
+            line = {'metric': metric_name('sweep'), 'value': f['value'], 'unit': f['unit'], 'n_gpus': world, 'steps': a.steps, 'warmup': warm,
+                    'ms_per_step': f['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+                    'data': 'synthetic', 'config': f['config'], 'roofline': f['roofline'],
+                    'cpu_baseline': None if a.no_cpu_baseline else cpu_baseline('dncnn', weights), 'psnr_db': f['psnr_db']}
+            print(json.dumps(line))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     w = Workload(a.workload, B, rank, a, weights)
     if a.host_minibatches:
@@ -377,7 +472,6 @@ def main():
         a.steps = -(-a.steps // T2) * T2
         a.warmup = -(-max(a.warmup, 1) // T2) * T2
     dt = measure(w, a.steps, a.warmup, sync_all, a.graph)
-    cdev = 'cuda' if (dist is None or a.backend == 'nccl') else 'cpu'      # where collective buffers live
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -419,6 +513,14 @@ def main():
                                                'after_timed_steps_mean': float(np.mean(tr2[-1]))}}
                 del w2
                 torch.cuda.empty_cache()
+            # config 5 on one GPU: the sweep driver with its gather inside the clock (the N > 1 runs are `--workload sweep --gpus N`)
+            dt5, warm5, w5, got5 = run_sweep_bench(rank, world, weights, 20, 10, sync_all, None, cdev)
+            f5 = sweep_fields(dt5, 20, w5, got5, 1)
+            secondary['sweep'] = {'metric': metric_name('sweep'), 'value': f5['value'], 'unit': f5['unit'], 'steps': 20, 'warmup': warm5,
+                                  'ms_per_step': f5['ms_per_step'], 'dtype': 'f32', 'scaling': 'strong', 'config': f5['config'],
+                                  'roofline': f5['roofline'], 'psnr_db': f5['psnr_db']}
+            del w5, got5
+            torch.cuda.empty_cache()
         cpu = None
         if not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(a.workload, weights)

@@ -31,6 +31,20 @@
 #include "fft.h"
 #include <cstdlib>
 
+// Diagnostic build (-DPNP_FUSED_CLOCK, tools/fused_clock.py): thread 0 of every workgroup stamps the shader clock at the phase
+// boundaries, so the phases can be timed in steady state (workgroups of a full launch are out of step with each other, unlike
+// the PNP_FUSED_STOP builds where every CU is in the same phase and the loads of all of them saturate HBM together).
+#ifdef PNP_FUSED_CLOCK
+#define PNP_STAMP_MAXB 4096
+__device__ unsigned long long g_fused_stamps[PNP_STAMP_MAXB * 16];
+#define PNP_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < PNP_STAMP_MAXB) g_fused_stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int pnp_debug_fused_stamps(unsigned long long* host_out, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_stamps), (size_t)nblocks * 16 * sizeof(unsigned long long));
+}
+#else
+#define PNP_STAMP(k) do { } while (0)
+#endif
+
 namespace pnp {
 
 constexpr int FN = 256;                                   // image side
@@ -219,12 +233,14 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
     // twiddles: requested before the operands (twv above), landed with them; the barrier also orders the selector bits
     if ((int)threadIdx.x < FN) twl[threadIdx.x] = twv;
     __syncthreads();
+    PNP_STAMP(1);
     if (STOP == 10) return;                                 // (diagnostic: the operand loads of phase 1 alone)
 #pragma unroll
     for (int p = 0; p < FP; ++p) {
         fft256<false>(Z[p], twl, scr, l);
         asm volatile("" ::: "memory");
     }
+    PNP_STAMP(2);
     if (STOP == 1) return;
 
     // ------------------------------------------------------------------ 2: columns, two halves
@@ -271,6 +287,7 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
             }
     }
     __syncthreads();
+    PNP_STAMP(3);
     if (STOP == 2) return;
 
     // ------------------------------------------------------------------ 3: rows inverse + epilogue (in place in Z)
@@ -280,6 +297,7 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
         fft256<true>(Z[p], twl, scr, l);
         asm volatile("" ::: "memory");
     }
+    PNP_STAMP(4);
 #pragma unroll
     for (int p = 0; p < FP; ++p)
 #pragma unroll
@@ -371,6 +389,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     // (the twiddle table goes to LDS inside fused_gradient, under the operand loads of phase 1)
     if (alpha_vec != nullptr) scale *= alpha_vec[prob];
 
+    PNP_STAMP(0);
     cx<float> Z[FP][16];
     fused_gradient<(STOP == 1 || STOP == 2 || STOP == 10) ? STOP : 0, OUTER>(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
                    yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
@@ -396,6 +415,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
         return;
     }
 
+    PNP_STAMP(5);
     // ------------------------------------------------------------------ 4: row-pair layout -> column layout
     // wave wv owns image columns [16 wv, 16 wv + 16) and [128 + 16 wv, ...); lane = column + 16 * chunk keeps rows
     // [64 chunk, 64 chunk + 64) of both
@@ -443,6 +463,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
         }
     };
     __syncthreads();                                            // the re-layout reads of every wave are done
+    PNP_STAMP(6);
     if (want_err) dma_xrec(0);
     // sigma_est = mean over the 256 columns of the per-column MAD estimate
     {
@@ -459,12 +480,14 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
         __syncthreads();
     }
     const float sigma_est = sig_sh;
+    PNP_STAMP(7);
     if (sigma_out != nullptr && t == 0) sigma_out[prob] = sigma_est;
     if (DENOISE) {
         const float sigma = sigma_est > 0.f ? sigma_est * sigma_modifier : fallback_sigma;
         haar_bayes_shrink<float, FN>(x[0], sigma * sigma);
         haar_bayes_shrink<float, FN>(x[1], sigma * sigma);
     }
+    PNP_STAMP(8);
     double err = 0.0;
     const float* xl = ldf + (64 * q) * 128 + 16 * wv + cl;      // this lane's column in the staged [row][128] block
     if (want_err) {
@@ -494,6 +517,10 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
             sse_out[prob] = s;
         }
     }
+#ifdef PNP_FUSED_CLOCK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PNP_STAMP(9);
 }
 
 // plan internals live in csmri.hip (pnp_csmri_svrg_step / pnp_csmri_grad_sel); the kernel only needs the plan's twiddle table.

@@ -361,6 +361,7 @@ class TVProx:
                     xrec=xrec, out=z, sse=sse_out, sigma_out=self.sig)
         return z
 
+    inplace = True                                              # writes its result into the iterate it was given
     # one-kernel iteration (pnp_csmri_svrg_step): the prox runs inside the gradient kernel
     fused_denoise = True
 
@@ -393,6 +394,7 @@ class DnCNNProx:
         self.plan.denoise(z, self.sigma, xrec=xrec, out=z, sse=sse_out)
         return z
 
+    inplace = True
     # one-kernel iteration: the gradient kernel makes the (ignored, F12) noise estimate; the network follows
     fused_denoise = False
 
@@ -409,6 +411,8 @@ class NLMProx:
     `self.sigma > 0` (the attribute the reference reads; default 1.0 here), else the decaying fixed strength.
     NLM cannot run in place: the prox ping-pongs between the engine's iterate and a buffer of its own and RETURNS the
     tensor that holds the result."""
+
+    inplace = False                                             # ping-pongs: a hipGraph of an outer iteration cannot hold it
 
     def __init__(self, sigma=1.0, sigma_modifier=1.0, decay=1.0, denoise_strength=0.0, patch_size=4, patch_distance=5):
         self.sigma, self.sigma_modifier, self.decay, self.denoise_strength = sigma, sigma_modifier, decay, denoise_strength
@@ -647,32 +651,46 @@ class SvrgEngine(_StochEngine):
                 else:
                     ops.axpbypcz(1.0, self.z, -lr, self.mu, out=self.z)
                 out = self.prox(self.z, b.xrec, self.sse_tmp)
-                assert out is self.z, 'graph capture needs an in-place prox'
+                if out is not self.z:
+                    raise ValueError('graph capture needs an in-place prox')
             ops.log_append(self.sse_tmp, self.sse_log, self.step_dev)
             ops.counter_add(self.step_dev, 1)
 
+    def graph_ok(self):
+        """Whether one outer iteration of this engine can be captured: constant step size, a prox that works in place and keeps
+        no host-side per-call state (TVProx with denoise_strength == 0, DnCNNProx; not NLMProx, which ping-pongs)."""
+        return (self.lr_decay == 1.0 and getattr(self.prox, 'inplace', False)
+                and getattr(self.prox, 'denoise_strength', 0.0) == 0.0)
+
     def capture(self):
-        """Capture one outer iteration into a hipGraph (torch.cuda.CUDAGraph on ROCm).  Needs lr_decay == 1, a
-        step count that is a multiple of T2, device-side minibatch draws and an in-place prox without host-side
-        per-call state (TVProx with denoise_strength == 0, DnCNNProx).  State is left untouched."""
-        assert self.lr_decay == 1.0 and self.s % self.T2 == 0 and self.n_prox == self.s
-        assert getattr(self.prox, 'denoise_strength', 0.0) == 0.0
+        """Capture one outer iteration into a hipGraph (torch.cuda.CUDAGraph on ROCm).  Needs `graph_ok()`, a step count that
+        is a multiple of T2 and device-side minibatch draws.  State is left untouched, also when the capture fails."""
+        if not self.graph_ok():
+            raise ValueError('this engine cannot be captured in a hipGraph (needs lr_decay == 1 and an in-place prox without '
+                             'host-side per-call state: TVProx with denoise_strength == 0 or DnCNNProx); step it eagerly')
+        if not (self.s % self.T2 == 0 and self.n_prox == self.s):
+            raise ValueError('capture() needs a step count that is a multiple of T2')
         self._set_dev_step(self.s)
         keep = (self.z.clone(), self.w.clone(), self.mu.clone(), self.sse_log.clone(), self.step_dev.clone())
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._outer_body()                                  # warm-up outside capture (lazy module loads)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._outer_body()
-        torch.cuda.synchronize()
-        for dst, src in zip((self.z, self.w, self.mu, self.sse_log, self.step_dev), keep):
-            dst.copy_(src)
-        if hasattr(self.prox, 't'):
-            self.prox.t -= 2 * self.T2
+        t_keep = getattr(self.prox, 't', None)
+        z_obj = self.z
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._outer_body()                              # warm-up outside capture (lazy module loads)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._outer_body()
+            torch.cuda.synchronize()
+        finally:
+            self.z = z_obj
+            for dst, src in zip((self.z, self.w, self.mu, self.sse_log, self.step_dev), keep):
+                dst.copy_(src)
+            if t_keep is not None:
+                self.prox.t = t_keep
         self.graph = g
         return g
 
@@ -749,11 +767,23 @@ class SagaEngine(_StochEngine):
         raise NotImplementedError('build a new SagaEngine (the table initialisation is part of the constructor)')
 
     def step(self, idx_s=None, r=None):
+        """r: the table row this step replaces -- one value for the whole batch, or one per problem (legacy-seeded sweeps:
+        every item follows its own np.random stream, and with masks of different sizes the streams drift apart)."""
         j = self._minibatch(idx_s, self.s)
-        r = int(self._rng.integers(self.hist)) if r is None else int(r)
+        if r is None:
+            r = int(self._rng.integers(self.hist))
         self.b.grad_stoch(self.z, self.mbs, j, out=self.g, alpha=1.0 / self.mb)
         lr = self.eta * self.lr_decay ** self.s
-        ops.saga_table_update(self.z, self.g, self.table[r], self.table[self.r_prev], self.tsum, lr, 1.0 / self.hist)
+        if np.ndim(r) == 0 and np.ndim(self.r_prev) == 0:
+            r = int(r)
+            ops.saga_table_update(self.z, self.g, self.table[r], self.table[self.r_prev], self.tsum, lr, 1.0 / self.hist)
+        else:
+            rv = np.broadcast_to(np.asarray(r, np.int64), (self.b.B,))
+            pv = np.broadcast_to(np.asarray(self.r_prev, np.int64), (self.b.B,))
+            for b in range(self.b.B):
+                ops.saga_table_update(self.z[b], self.g[b], self.table[int(rv[b]), b], self.table[int(pv[b]), b], self.tsum[b],
+                                      lr, 1.0 / self.hist)
+            r = rv.copy()
         self.r_prev = r
         self.z = self._prox(self.z)
         self.s += 1

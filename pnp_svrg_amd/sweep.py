@@ -46,6 +46,39 @@ def gather_results(local, dst=0, group=None):
     return sorted((r for part in out for r in part), key=lambda r: r['id'])
 
 
+def gather_device(z_local, meta_local, n_items, dst=0, group=None):
+    """The final gather as two tensor collectives (RCCL over xGMI when the group is NCCL): the reconstructions
+    z_local [n_local, H, W] (device tensor, any float dtype) and one small float64 row per item meta_local [n_local, K] whose
+    first column is the item id.  Ranks hold different numbers of items (round-robin shards), so rows are padded to
+    ceil(n_items / world).  Returns (z [n_items, H, W], meta [n_items, K]) in id order on rank `dst` (CPU tensors), None
+    elsewhere.  Single-process: the local data, sorted."""
+    meta_local = torch.as_tensor(meta_local, dtype=torch.float64).reshape(z_local.shape[0], -1)
+    if not (dist.is_available() and dist.is_initialized()):
+        order = torch.argsort(meta_local[:, 0])
+        return z_local.detach().cpu()[order], meta_local[order]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_dev = dist.get_backend(group) == 'nccl'
+    dev = z_local.device if on_dev else torch.device('cpu')
+    cap = -(-n_items // world)
+    zp = torch.zeros((cap,) + tuple(z_local.shape[1:]), dtype=z_local.dtype, device=dev)
+    mp = torch.full((cap, meta_local.shape[1]), -1.0, dtype=torch.float64, device=dev)
+    n = z_local.shape[0]
+    zp[:n] = z_local.to(dev)
+    mp[:n] = meta_local.to(dev)
+    zs = [torch.empty_like(zp) for _ in range(world)] if rank == dst else None
+    ms = [torch.empty_like(mp) for _ in range(world)] if rank == dst else None
+    dist.gather(zp, zs, dst=dst, group=group)
+    dist.gather(mp, ms, dst=dst, group=group)
+    if rank != dst:
+        return None
+    z, m = torch.cat(zs).cpu(), torch.cat(ms).cpu()
+    keep = m[:, 0] >= 0
+    z, m = z[keep], m[keep]
+    order = torch.argsort(m[:, 0])
+    assert order.numel() == n_items, 'every item exactly once'
+    return z[order], m[order]
+
+
 def run_sweep(items, runner, group=None):
     """Run `runner(my_items) -> [result dict per item]` on this rank's shard and gather on rank 0."""
     if dist.is_available() and dist.is_initialized():
@@ -58,12 +91,16 @@ def run_sweep(items, runner, group=None):
     return gather_results(res, 0, group)
 
 
+def _norm01(img):
+    x = np.asarray(img, np.float64)
+    return (x - x.min()) / (x.max() - x.min())
+
+
 def _csmri_item_generator(img, it, H, W):
     """One work item's data from a Generator stream keyed by the item (fast path of the sweeps): Bernoulli mask like
     the reference (problems/CSMRI.py:43-45), masked spectrum + real noise on the support (:29-33), |ifft2| init."""
     rng = np.random.default_rng(1000003 * it['seed'] + it['id'])
-    x = np.asarray(img, np.float64)
-    x = (x - x.min()) / (x.max() - x.min())
+    x = _norm01(img)
     mk = (rng.random((H, W)) < it['alpha']).astype(np.uint8)
     Y0 = mk * np.fft.fft2(x)
     sig = np.sqrt(np.linalg.norm(Y0.ravel()) / 10 ** (it['snr'] / 10) / H / W)
@@ -72,62 +109,220 @@ def _csmri_item_generator(img, it, H, W):
     return x, mk, Y, ((xi - xi.min()) / (xi.max() - xi.min())).ravel()
 
 
-def csmri_svrg_runner(images, denoiser_factory, eta, T2, mini_batch_size, n_inner, H=256, W=256, dtype=torch.float32,
-                      max_batch=128, seeding='generator', algorithm='svrg', variant='svrg', run_seed=1, keep_trace=False, graph=True):
-    """Default runner: CSMRI + pnp_svrg (true SVRG direction) on the batched engine.
-    images: list of HxW arrays.  ALL of a rank's items -- any mix of sampling ratios, i.e. masks with different
-    numbers of sampled points -- go through the engine together (chunks of max_batch): per-problem 1/M0 and
-    per-problem minibatch thresholds make the batch independent of alpha.
-    seeding='generator': per-item data from a Generator stream, minibatches drawn on the device;
-    seeding='legacy'   : per item exactly what the reference does -- np.random.seed(item seed), the CSMRI constructor's
-                         draws in its order (mask, noise; problems/CSMRI.py:12-41), then np.random.seed(run_seed) and one
-                         select_mb draw per inner iteration (algorithms/pnp_svrg.py:52) from the legacy stream -- so an
-                         item's trajectory equals the reference loop's (and the oracle's) on the same seeds.
-    graph=False steps eagerly where whole outer iterations would otherwise replay as hipGraphs (same results)."""
-    from .engine import CsmriBatch, make_engine
-    from . import problems as P
+def _minimal_kernel(H, W, kernel):
+    """The reference's "Minimal" / "Identity" blur vectors (problems/DeblurSR.py:80-93), already divided by N."""
+    Bk = np.zeros((H, W))
+    Bk[0, 0] = 1
+    if kernel == 'Minimal':
+        Bk[H // 2, H // 2] = Bk[H // 2, H // 3] = Bk[H // 2, H // 4] = 1
+        Bk /= 4
+    elif kernel != 'Identity':
+        raise ValueError(f'kernel {kernel!r}: "Minimal" or "Identity" (generator seeding; legacy seeding takes what problems.Deblur takes)')
+    return Bk.ravel() / (H * W)
 
-    def run(items):
-        results = []
-        for s0 in range(0, len(items), max_batch):
-            chunk = items[s0:s0 + max_batch]
-            xs, masks, Ys, xinits, idx = [], [], [], [], None
+
+PROBLEMS = ('csmri', 'deblur', 'pr')
+ALGORITHMS = ('gd', 'sgd', 'svrg', 'saga', 'sarah')
+_REF_NAMES = {'csmri': 'CSMRI', 'deblur': 'DeblurSR', 'pr': 'PR', 'tv': 'TV', 'nlm': 'NLM', 'dncnn': 'CNN'}
+
+
+def deblur_scale_percent(alpha):
+    """item alpha (fraction of the full-resolution measurements, 0.1 .. 1.0) -> Deblur's scale_percent, as the reference's
+    get_problem does with its alpha in 1 .. 10 (script_diff_sampratio_set12.py:45-46: int(alpha * 10))."""
+    return int(round(alpha * 100))
+
+
+def pr_num_meas(alpha, H, W):
+    """item alpha (measurements per pixel) -> PhaseRetrieval's num_meas (script_diff_sampratio_set12.py:47-48)."""
+    return int(alpha * H * W)
+
+
+def make_prox(denoiser, **kw):
+    """'tv' | 'nlm' -> a fresh engine prox (denoisers/TV.py, NLM.py semantics); a callable is called (e.g. a DnCNNProx factory)."""
+    from .engine import TVProx, NLMProx
+    if callable(denoiser):
+        return denoiser()
+    if denoiser == 'tv':
+        return TVProx(**kw)
+    if denoiser == 'nlm':
+        return NLMProx(**kw)
+    raise ValueError(f'unknown denoiser {denoiser!r}: "tv", "nlm" or a factory')
+
+
+def make_runner(images, problem='csmri', algorithm='svrg', denoiser='tv', *, eta, n_inner, mini_batch_size=None, T2=None,
+                hist_size=50, H=256, W=256, dtype=torch.float32, max_batch=128, seeding='generator', variant='svrg', run_seed=1,
+                keep_trace=False, graph=True, kernel='Minimal', lr_decay=1.0, denoiser_kwargs=None):
+    """Runner for `run_sweep` / `grid_search` over any cell of the reference's sweep (script_diff_sampratio_set12.py:23-25,
+    41-51, 64-131): problem in {'csmri', 'deblur', 'pr'} x algorithm in {'gd', 'sgd', 'svrg', 'saga', 'sarah'} x denoiser in
+    {'tv', 'nlm', factory}; `n_inner` inner iterations (prox evaluations of the stepped iterate) per item, hyper-parameters
+    eta, mini_batch_size, T2 (svrg, sarah), hist_size (saga) -- the keys a search grid varies.
+
+    A rank's items run as batches on the engines of `engine.py`: CSMRI items of ANY mix of sampling ratios together (per-problem
+    1/M0 and minibatch thresholds); Deblur / PR items are grouped by alpha, which fixes the operator's shape (scale_percent =
+    100 alpha; num_meas = alpha H W).
+    seeding='generator': per-item data from a Generator stream keyed by the item, minibatches drawn on the device;
+    seeding='legacy'   : per item exactly the reference's RNG use -- np.random.seed(item seed), the problem constructor's draws
+                         in its order, np.random.seed(run_seed), then the loop's draws in ITS order (one select_mb per inner
+                         iteration; pnp_saga: one select_mb for the table, then select_mb + np.random.choice(hist_size, 1) per
+                         iteration, algorithms/pnp_saga.py:25-29,43-47) -- so an item's trajectory equals the reference loop's
+                         (and the oracle's) on the same seeds."""
+    from . import engine as E
+    from . import problems as P
+    if problem not in PROBLEMS or algorithm not in ALGORITHMS:
+        raise ValueError(f'problem in {PROBLEMS}, algorithm in {ALGORITHMS}')
+    if algorithm != 'gd' and mini_batch_size is None:
+        raise ValueError('mini_batch_size is required')
+    if algorithm in ('svrg', 'sarah') and T2 is None:
+        raise ValueError('T2 is required')
+    mb, dkw = mini_batch_size, dict(denoiser_kwargs or {})
+
+    def group_key(it):
+        return None if problem == 'csmri' else it['alpha']
+
+    def build_generator(chunk):
+        a = chunk[0]['alpha']
+        if problem == 'csmri':
+            d = [_csmri_item_generator(images[it['image']], it, H, W) for it in chunk]
+            return E.CsmriBatch(np.stack([t[0] for t in d]), np.stack([t[1] for t in d]), np.stack([t[2] for t in d]),
+                                np.stack([t[3] for t in d]).reshape(len(chunk), -1), dtype=dtype)
+        if problem == 'deblur':
+            if deblur_scale_percent(a) != 100:
+                raise ValueError('generator seeding builds scale_percent == 100 Deblur items; use seeding="legacy" for the bilinear operator')
+            Bk = _minimal_kernel(H, W, kernel)
+            FB = np.fft.fft(Bk)
+            xs, Ys, xi = [], [], []
+            for it in chunk:
+                rng = np.random.default_rng(1000003 * it['seed'] + it['id'])
+                x = _norm01(images[it['image']])
+                Y0 = np.real(np.fft.ifft(np.fft.fft(x.ravel()) * FB)) * np.sqrt(H * W)        # DeblurSR.py:119-120
+                sig = np.sqrt(np.linalg.norm(Y0) / 10 ** (it['snr'] / 10) / H / W)
+                xs.append(x); Ys.append(Y0 + rng.normal(0, sig, H * W)); xi.append(rng.uniform(0.0, 1.0, H * W))
+            return E.DeblurBatch(np.stack(xs), Bk, np.stack(Ys), np.stack(xi), dtype=dtype)
+        M = pr_num_meas(a, H, W)
+        xs, As, Ys, xi = [], [], [], []
+        for it in chunk:
+            rng = np.random.default_rng(1000003 * it['seed'] + it['id'])
+            x = _norm01(images[it['image']])
+            A = rng.standard_normal((M, H * W))
+            Y0 = np.absolute(A @ x.ravel())
+            sig = np.sqrt(np.linalg.norm(Y0) / 10 ** (it['snr'] / 10) / H / W)
+            Y = Y0 + rng.normal(0, sig, M)
+            v, lead, lead_old, prev = np.full(H * W, 2.0), 1.0, 2.0, np.ones(H * W)          # PR.py:50-63 (host: small N)
+            while abs(lead - lead_old) > 1e-5 and np.linalg.norm(v - prev) > 1e-5:
+                lead_old, prev = lead, v
+                v = A.T @ (Y * (A @ prev)) / M
+                lead = v.max()
+                v = v / lead
+            x0 = np.sqrt(lead) * v / np.linalg.norm(v) * np.linalg.norm(x.ravel())
+            xs.append(x); As.append(A); Ys.append(Y); xi.append((x0 - x0.min()) / (x0.max() - x0.min()))
+        return E.PrBatch(np.stack(xs), np.stack(As), np.stack(Ys), np.stack(xi), dtype=dtype)
+
+    def build_legacy(chunk):
+        """-> (batch, draws): per item the reference's constructor on its seed, then the loop's RNG draws on run_seed."""
+        probs, draws = [], []
+        n_mb = 0 if algorithm == 'gd' else n_inner + (1 if algorithm == 'saga' else 0)
+        for it in chunk:
+            np.random.seed(it['seed'])
+            img = images[it['image']]
+            if problem == 'csmri':
+                p = P.CSMRI(None, H=H, W=W, sample_prob=it['alpha'], snr=it['snr'], img=img, upload=False)
+            elif problem == 'deblur':
+                p = P.Deblur(None, H=H, W=W, kernel=kernel, scale_percent=deblur_scale_percent(it['alpha']), snr=it['snr'], img=img,
+                             dtype=dtype)
+            else:
+                p = P.PhaseRetrieval(None, H=H, W=W, num_meas=pr_num_meas(it['alpha'], H, W), snr=it['snr'], img=img, dtype=dtype)
+            np.random.seed(run_seed)
+            idx, rs = np.empty((n_mb, mb if n_mb else 0), np.int32), np.zeros(n_inner, np.int64)
+            for s in range(n_mb):
+                idx[s] = np.flatnonzero(p.select_mb(mb))
+                if algorithm == 'saga' and s > 0:
+                    rs[s - 1] = np.random.choice(hist_size, 1).item()
+            probs.append(p)
+            draws.append((idx, rs))
+        cls = {'csmri': E.CsmriBatch, 'deblur': E.DeblurBatch, 'pr': E.PrBatch}[problem]
+        return cls.from_problems(probs, dtype=dtype), draws
+
+    class _Chunk:
+        """One batch of a rank's items on its engine: built (data in HBM) by `prepare`, advanced by `advance`."""
+
+        def __init__(self, chunk):
+            self.items = chunk
             if seeding == 'legacy':
-                idx = np.empty((n_inner, len(chunk), mini_batch_size), np.int32)
-                for j, it in enumerate(chunk):
-                    np.random.seed(it['seed'])
-                    p = P.CSMRI(None, H=H, W=W, sample_prob=it['alpha'], snr=it['snr'], img=images[it['image']], upload=False)
-                    xs.append(p.Xrec); masks.append(p.mask); Ys.append(p.Y); xinits.append(p.Xinit)
-                    np.random.seed(run_seed)
-                    for s in range(n_inner):
-                        idx[s, j] = np.flatnonzero(p.select_mb(mini_batch_size))
+                self.batch, draws = build_legacy(chunk)
+                self.idx_d = torch.from_numpy(np.stack([d[0] for d in draws], axis=1)).to(self.batch.device) if algorithm != 'gd' else None
+                self.rs = np.stack([d[1] for d in draws], axis=1)                  # [n_inner][B]
             else:
-                for it in chunk:
-                    x, mk, Y, xi = _csmri_item_generator(images[it['image']], it, H, W)
-                    xs.append(x); masks.append(mk); Ys.append(Y); xinits.append(xi)
-            batch = CsmriBatch(np.stack(xs), np.stack(masks), np.stack(Ys), np.stack(xinits).reshape(len(chunk), -1), dtype=dtype)
-            eng = make_engine(batch, denoiser_factory(), eta, T2, mini_batch_size, variant=variant, algorithm=algorithm,
-                              seed=chunk[0]['id'] + 1)
-            idx_d = torch.from_numpy(idx).to(batch.device) if idx is not None else None
+                self.batch, self.idx_d, self.rs = build_generator(chunk), None, None
+            kw = dict(seed=chunk[0]['id'] + 1)
+            if algorithm == 'saga' and self.idx_d is not None:
+                kw['idx0'] = self.idx_d[0]
+            self.eng = E.make_engine(self.batch, make_prox(denoiser, **dkw), eta, T2, mb, lr_decay=lr_decay, variant=variant,
+                                     algorithm=algorithm, hist_size=hist_size, **kw)
+            self.done = 0
+
+        def advance(self, n):
+            eng, idx_d = self.eng, self.idx_d
             # device-drawn minibatches: whole outer iterations replay as hipGraphs (bit-identical to stepping; a rank's share
-            # of a sweep is a small batch, where the ~25 launches of an inner iteration are a tenth of its time)
-            if (graph and idx_d is None and hasattr(eng, 'run_outer') and n_inner % T2 == 0 and n_inner > T2
-                    and getattr(eng, 'lr_decay', 1.0) == 1.0 and getattr(eng.prox, 'denoise_strength', 0.0) == 0.0):
-                eng.run_outer(n_inner // T2)
+            # of a sweep is a small batch, where the ~25 launches of an inner iteration are a tenth of its time) -- when the
+            # engine can be captured at all (an NLM prox ping-pongs between buffers and cannot: eager steps)
+            if (graph and idx_d is None and hasattr(eng, 'run_outer') and n % T2 == 0 and eng.s % T2 == 0
+                    and (n > T2 or eng.graph is not None) and eng.graph_ok()):
+                eng.run_outer(n // T2)
             else:
-                for s in range(n_inner):
-                    eng.step(idx_d[s]) if idx_d is not None else eng.step()
-            tr = eng.psnr_trace()
-            psnr0 = batch.psnr_init()
-            z = eng.z.cpu().numpy()
-            for j, it in enumerate(chunk):
+                for s in range(self.done, self.done + n):
+                    if idx_d is None:
+                        eng.step()
+                    elif algorithm == 'saga':
+                        eng.step(idx_d[s + 1], r=self.rs[s])
+                    else:
+                        eng.step(idx_d[s])
+            self.done += n
+
+        def results(self):
+            tr = self.eng.psnr_trace()
+            psnr0 = self.batch.psnr_init()
+            z = self.eng.z.cpu().numpy()
+            out = []
+            for j, it in enumerate(self.items):
                 r = {'id': it['id'], 'item': it, 'psnr_init': float(psnr0[j]), 'psnr_final': float(tr[-1, j]),
-                     'loss': float(psnr0[j] - tr[-1, j]), 'z': z[j], 'M0': int(batch.M0[j])}
+                     'loss': float(psnr0[j] - tr[-1, j]), 'z': z[j]}
+                if problem == 'csmri':
+                    r['M0'] = int(self.batch.M0[j])
                 if keep_trace:
                     r['psnr_trace'] = tr[:, j].copy()
-                results.append(r)
-        return sorted(results, key=lambda r: r['id'])
+                out.append(r)
+            return out
+
+    def prepare(items):
+        """Build this rank's batches (problem data resident in HBM, engines constructed): everything before the iterations."""
+        groups = {}
+        for it in items:
+            groups.setdefault(group_key(it), []).append(it)
+        return [_Chunk(g[s0:s0 + max_batch]) for g in groups.values() for s0 in range(0, len(g), max_batch)]
+
+    def advance(state, n):
+        for c in state:
+            c.advance(n)
+
+    def collect(state):
+        return sorted((r for c in state for r in c.results()), key=lambda r: r['id'])
+
+    def run(items):
+        state = prepare(items)
+        advance(state, n_inner)
+        return collect(state)
+
+    run.prepare, run.advance, run.collect = prepare, advance, collect
+    run.names = (_REF_NAMES[problem], 'CNN' if callable(denoiser) else _REF_NAMES.get(denoiser, str(denoiser)), 'pnp_' + algorithm)
     return run
+
+
+def csmri_svrg_runner(images, denoiser_factory, eta, T2, mini_batch_size, n_inner, H=256, W=256, dtype=torch.float32,
+                      max_batch=128, seeding='generator', algorithm='svrg', variant='svrg', run_seed=1, keep_trace=False, graph=True):
+    """The config-5 runner (CSMRI + pnp_svrg, true SVRG direction): `make_runner(problem='csmri')` with a prox factory."""
+    return make_runner(images, 'csmri', algorithm, denoiser_factory, eta=eta, n_inner=n_inner, mini_batch_size=mini_batch_size, T2=T2,
+                       H=H, W=W, dtype=dtype, max_batch=max_batch, seeding=seeding, variant=variant, run_seed=run_seed,
+                       keep_trace=keep_trace, graph=graph)
 
 
 def write_csv(path, results, problem='csmri', denoiser='', algorithm='pnp_svrg', params=''):

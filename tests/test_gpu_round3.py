@@ -125,3 +125,110 @@ def test_dncnn_prox_full_length_vs_oracle(g_csmri):
         tr = eng.psnr_trace()[:, 0]
         assert np.abs(tr - ref).max() <= PSNR_TOL, (fused, np.abs(tr - ref).max())
         assert np.abs(eng.z.double().cpu().numpy().ravel() - ro['z']).max() <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ general sweep runner
+def _smooth_images(n, count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        x = rng.random((n, n))
+        p = np.pad(x, 2, mode='wrap')
+        out.append(sum(p[i:i + n, j:j + n] for i in range(5) for j in range(5)) / 25.0)
+    return out
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_sweep_runner_deblur_nlm_saga_vs_oracle(dtype):
+    """One cell of the reference's sweep beyond CSMRI (script_diff_sampratio_set12.py:23-25: DeblurSR x NLM x pnp_saga): three
+    legacy-seeded items in ONE batch through `sweep.make_runner`, each against `oracle.loops.pnp_saga` on the same seeds
+    (constructor draws, then per iteration select_mb + np.random.choice(hist_size, 1): every item its own stream)."""
+    from pnp_svrg_amd import sweep
+    from oracle import denoise as od, problems as op
+    n, mb, hist, n_it, eta = 64, 300, 4, 5, 2e8
+    imgs = _smooth_images(n, 2, 3)
+    items = [{'id': 0, 'image': 0, 'alpha': 1.0, 'snr': 20.0, 'seed': 0}, {'id': 1, 'image': 1, 'alpha': 1.0, 'snr': 20.0, 'seed': 5},
+             {'id': 2, 'image': 0, 'alpha': 1.0, 'snr': 10.0, 'seed': 2}]
+    run = sweep.make_runner(imgs, 'deblur', 'saga', 'nlm', eta=eta, n_inner=n_it, mini_batch_size=mb, hist_size=hist, H=n, W=n,
+                            dtype=dtype, seeding='legacy', keep_trace=True)
+    assert run.names == ('DeblurSR', 'NLM', 'pnp_saga')
+    res = sweep.run_sweep(items, run)
+    for it, r in zip(items, res):
+        np.random.seed(it['seed'])
+        p = op.Deblur(None, H=n, W=n, kernel='Minimal', scale_percent=100, snr=it['snr'], img=imgs[it['image']])
+        d = od.NLMDenoiser()
+        d.sigma = 1.0
+        np.random.seed(1)
+        ro = ol.pnp_saga(p, d, eta, 5 * n_it - 1, mb, hist_size=hist, converge_check=False, clock=ol.CountingClock())
+        ref = np.array(ro['psnr_per_iter'])
+        assert len(ref) == n_it + 1 and r['psnr_init'] == ref[0]
+        if dtype == torch.float64:
+            assert list(r['psnr_trace']) == list(ref[1:])
+            assert np.abs(r['z'].ravel() - ro['z']).max() <= 1e-9
+        else:
+            assert np.abs(r['psnr_trace'] - ref[1:]).max() <= PSNR_TOL
+            assert np.abs(r['z'].ravel() - ro['z']).max() <= 1e-3
+    assert len({tuple(r['psnr_trace']) for r in res}) == 3                  # three different problems
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_sweep_runner_pr_tv_sarah_vs_oracle(dtype):
+    """PR (32 x 32, num_meas = alpha * 1024 as script_diff_sampratio_set12.py:47-48) x TV x pnp_sarah through `sweep.make_runner`:
+    items of two oversampling ratios (two batches, grouped by alpha), legacy seeding, each against `oracle.loops.pnp_sarah`."""
+    from pnp_svrg_amd import sweep
+    from oracle import denoise as od, problems as op
+    n, mb, T2, n_it, eta = 32, 200, 3, 7, 0.05
+    imgs = _smooth_images(n, 2, 7)
+    items = [{'id': 0, 'image': 0, 'alpha': 2.0, 'snr': 20.0, 'seed': 0}, {'id': 1, 'image': 1, 'alpha': 3.0, 'snr': 20.0, 'seed': 1},
+             {'id': 2, 'image': 1, 'alpha': 2.0, 'snr': 20.0, 'seed': 4}]
+    run = sweep.make_runner(imgs, 'pr', 'sarah', 'tv', eta=eta, n_inner=n_it, mini_batch_size=mb, T2=T2, H=n, W=n, dtype=dtype,
+                            seeding='legacy', keep_trace=True, lr_decay=0.9)
+    res = sweep.run_sweep(items, run)
+    assert [r['id'] for r in res] == [0, 1, 2]
+    o, j = (n_it - 1) // T2, (n_it - 1) % T2
+    for it, r in zip(items, res):
+        np.random.seed(it['seed'])
+        p = op.PhaseRetrieval(None, H=n, W=n, num_meas=int(it['alpha'] * n * n), snr=it['snr'], img=imgs[it['image']])
+        np.random.seed(1)
+        ro = ol.pnp_sarah(p, od.TVDenoiser(), eta, 1 + o * (5 + 5 * T2) + 5 + 5 * j + 1, T2, mb, converge_check=False,
+                          clock=ol.CountingClock(), lr_decay=0.9)
+        ref = np.array(ro['psnr_per_iter'])                      # outer prox entries included, like the engine's log
+        assert len(ref) == len(r['psnr_trace'])
+        if dtype == torch.float64:
+            assert np.abs(r['psnr_trace'] - ref).max() <= 1e-9
+            assert np.abs(r['z'].ravel() - ro['z']).max() <= 1e-8
+        else:
+            assert np.abs(r['psnr_trace'] - ref).max() <= PSNR_TOL
+            assert np.abs(r['z'].ravel() - ro['z']).max() <= 2e-3
+
+
+def test_sweep_runner_cells_and_hist_size_grid(tmp_path):
+    """Every (problem, algorithm) cell steps through `make_runner` with generator seeding and device draws (NLM with pnp_svrg
+    included: it cannot be captured in a hipGraph and must fall back to eager stepping -- ADVICE r2), and `hist_size` is a
+    searchable key of `grid_search` for pnp_saga (script_diff_snr_set12.py search space)."""
+    from pnp_svrg_amd import sweep
+    n = 64
+    imgs = _smooth_images(n, 2, 11)
+    items = sweep.make_items(2, [1.0], [20.0])
+    for problem, eta, mb in (('csmri', 5e2, 100), ('deblur', 2e8, 300)):
+        for algo in sweep.ALGORITHMS:
+            its = items if problem == 'deblur' else sweep.make_items(2, [0.3, 0.5], [20.0])
+            run = sweep.make_runner(imgs, problem, algo, 'tv', eta=eta, n_inner=8, mini_batch_size=mb, T2=4, hist_size=3, H=n, W=n)
+            res = sweep.run_sweep(its, run)
+            assert len(res) == len(its) and all(np.isfinite(r['psnr_final']) for r in res), (problem, algo)
+    # NLM prox under pnp_svrg with device draws: 8 = 2 x T2 inner iterations would take the graph path if it could
+    run = sweep.make_runner(imgs, 'csmri', 'svrg', 'nlm', eta=5e2, n_inner=8, mini_batch_size=100, T2=4, H=n, W=n)
+    res = sweep.run_sweep(sweep.make_items(2, [0.4], [20.0]), run)
+    assert all(np.isfinite(r['psnr_final']) for r in res)
+    its = [{'id': 0, 'image': 0, 'alpha': 2.0, 'snr': 20.0, 'seed': 0}, {'id': 1, 'image': 1, 'alpha': 2.0, 'snr': 20.0, 'seed': 0}]
+    pr_imgs = _smooth_images(32, 2, 5)
+    res = sweep.run_sweep(its, sweep.make_runner(pr_imgs, 'pr', 'svrg', 'tv', eta=0.05, n_inner=6, mini_batch_size=200, T2=3, H=32, W=32))
+    assert all(np.isfinite(r['psnr_final']) for r in res)
+
+    def mk(eta, hist_size):
+        return sweep.make_runner(imgs, 'deblur', 'saga', 'tv', eta=eta, n_inner=6, mini_batch_size=300, hist_size=hist_size, H=n, W=n)
+    rows = sweep.grid_search(items, mk, {'eta': [1e8, 3e8], 'hist_size': [2, 5]})
+    assert [r['id'] for r in rows] == [0, 1] and all(set(r['params']) == {'eta', 'hist_size'} for r in rows)
+    sweep.write_tuning_csv(str(tmp_path / 't.csv'), rows, problem='DeblurSR', denoiser='TV', algorithm='pnp_saga')
+    txt = (tmp_path / 't.csv').read_text().splitlines()
+    assert txt[0] == 'Results:' and txt[1].startswith('DeblurSR,TV,pnp_saga,1.0,20.0,') and ',PARAMETERS:,eta,' in txt[1] and ',hist_size,' in txt[1]

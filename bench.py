@@ -43,9 +43,8 @@ NET_SIGMA = 15
 # pnp_saga.py:29-31) the direction keeps that bias for ~hist steps, hence the small step size
 SAGA_ETA, SAGA_MB, SAGA_HIST, SAGA_SNR = 5e6, 3000, 50, 20.0
 FLOP_MID_PER_IMAGE = 2 * 9 * 64 * 64 * H * W          # one 64->64 3x3 conv layer, direct form
-WINOGRAD_REDUCTION = {'5': 4.0, '4': 2.0, '1': 1.5, '0': 1.0}    # F(4x4,3x3) executes 1/4 of the direct form's multiply-adds, F(4,3) / F(2,3) along x 1/2 / 2/3
+WINOGRAD_REDUCTION = {'5': 4.0, '1': 1.5, '0': 1.0}    # F(4x4,3x3) executes 1/4 of the direct form's multiply-adds, F(2,3) along x 2/3
 F32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
-F16_MFMA_PEAK_TFLOPS = 2500.0                         # same guide: ~2.5 PF dense bf16/f16 (only for --conv f16x3)
 F32_VALU_PEAK_TFLOPS = 157.3                          # same guide: vector f32 FMA peak (NLM prox)
 HBM_PEAK_GBS = 8000.0
 TV_BYTES_PER_ITER = 2368 * 1024                       # algorithmic bytes of one config-2 problem-iteration
@@ -68,10 +67,9 @@ def parse():
                     help='gloo + PNP_BENCH_ONE_DEVICE=1 rehearses the N>1 path with all ranks on GPU 0')
     ap.add_argument('--graph', action='store_true',
                     help='replay one outer iteration (T2 steps) per hipGraph launch; --steps/--warmup are rounded up to multiples of T2')
-    ap.add_argument('--conv', default=None, choices=['f32-winograd44', 'f32-winograd4', 'f32-winograd', 'f32-direct', 'f16x3'],
-                    help='conv kernel of the DnCNN prox (default: f32-winograd44 = F(4x4,3x3), or PNP_DNCNN_WINOGRAD; f32-winograd4 = F(4,3) along x, f32-winograd = F(2,3)).  f16x3 = opt-in '
-                         'split-fp16 products with fp32 accumulation (fp32-class accuracy, not the reference arithmetic): '
-                         'the line then says dtype "f32 via 3 x f16 split" and prices the conv against the f16 matrix peak')
+    ap.add_argument('--conv', default=None, choices=['f32-winograd44', 'f32-winograd', 'f32-direct'],
+                    help='conv kernel of the DnCNN prox (default: f32-winograd44 = F(4x4,3x3), or PNP_DNCNN_WINOGRAD; f32-winograd = F(2,3) along x, '
+                         'f32-direct = implicit GEMM, bit for bit an fmaf chain)')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
     ap.add_argument('--no-fold', action='store_true', help='A/B: the outer full-gradient refresh as launches of its own instead of '
                                                             'folded into the first inner iteration (one-kernel iteration only)')
@@ -209,19 +207,10 @@ class Workload:
             flops = FLOP_MID_PER_IMAGE * B
             alg = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             mode = os.environ.get('PNP_DNCNN_WINOGRAD', '5')
-            if mode == '3':
-                ex = 3.0 * alg                                  # three fp16 MFMAs per product
-                return {'bound': 'mfma',
-                        'kernel': 'pnp::k_mid_f16x3 (64->64 3x3 conv, every fp32 operand split into two fp16 terms, three '
-                                  'v_mfma_f32_16x16x32_f16 per product, fp32 accumulation; OPT-IN, not the reference arithmetic)',
-                        'achieved': round(ex, 2), 'peak': F16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ex / F16_MFMA_PEAK_TFLOPS, 4), 'traffic': None, 'launch_ms': round(ms, 4),
-                        'launches_timed': launches, 'flops_per_launch': 3 * flops, 'algorithmic_tflops': round(alg, 2)}
             red = WINOGRAD_REDUCTION.get(mode, 4.0)
             ex = alg / red
             return {'bound': 'mfma',
                     'kernel': {'5': 'pnp::w44::k_mid_wino44 (64->64 3x3 conv, Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32)',
-                               '4': 'pnp::w4::k_mid_wino4 (64->64 3x3 conv, Winograd F(4,3) along x on v_mfma_f32_16x16x4_f32)',
                                '1': 'pnp::k_mid_wino (64->64 3x3 conv, Winograd F(2,3) along x on v_mfma_f32_16x16x4_f32)',
                                '0': 'pnp::k_mid (64->64 3x3 conv, direct implicit GEMM on v_mfma_f32_16x16x4_f32)'}.get(mode, mode),
                     # achieved / frac: what the matrix cores EXECUTE per second against their peak
@@ -436,7 +425,7 @@ def main():
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE {world}: using WORLD_SIZE', file=sys.stderr)
 
     if a.conv is not None:
-        os.environ['PNP_DNCNN_WINOGRAD'] = {'f32-winograd44': '5', 'f32-winograd4': '4', 'f32-winograd': '1', 'f32-direct': '0', 'f16x3': '3'}[a.conv]
+        os.environ['PNP_DNCNN_WINOGRAD'] = {'f32-winograd44': '5', 'f32-winograd': '1', 'f32-direct': '0'}[a.conv]
     from pnp_svrg_amd import ops
     ops.require_gpu()
 
@@ -530,7 +519,7 @@ def main():
             'value': round(value, 2), 'unit': 'inner-iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32 via 3 x f16 split products (opt-in)' if (a.workload == 'dncnn' and os.environ.get('PNP_DNCNN_WINOGRAD') == '3') else 'f32',
+            'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': workload_desc(a.workload, wdesc),
                        'batch_per_gpu': B, 'problems_total': world * B, 'parallelism': f'replicas x{world} (no data-path collective)'},

@@ -221,14 +221,14 @@ int pnp_dncnn_plan_destroy(pnp_dncnn_plan* plan);
  * bias-free ReLU nets: the MMO `simple_CNN` (denoisers/MMODenoise.py:73-101: every conv has a bias, LeakyReLU(0.01),
  * b_mid goes in through plan_create).  b_first: HOST [64] or NULL (= zeros); negative_slope 0 = ReLU.         */
 int pnp_dncnn_set_affine(pnp_dncnn_plan* plan, const float* b_first, float b_last, float negative_slope);
-/* Conv kernel choice for the 64->64 layers (all fp32 on the f32 matrix cores unless noted):
- *   5 = Winograd F(4x4,3x3) (default where H % 8 == 0 and W % 64 == 0; executes 1/4 of the direct form's multiply-adds),
- *   4 = Winograd F(4,3) along x (1/2; needs H % 4 == 0 and W % 64 == 0), 1 = Winograd F(2,3) along x (2/3),
- *   0 = direct implicit GEMM (bit-for-bit an fmaf chain),
- *   3 = OPT-IN split-fp16 layers (every fp32 operand as two fp16 terms, three fp16 MFMAs per product, fp32 accumulation:
- *       fp32-class accuracy, but not the reference's arithmetic).
- * The default comes from the environment variable PNP_DNCNN_WINOGRAD (unset = 5, falling back to 4, then 1, where the
- * image size does not allow it) at plan creation.                                                                   */
+/* Conv kernel choice for the 64->64 layers (all fp32 on the f32 matrix cores):
+ *   5 = Winograd F(4x4,3x3) (default where H % 8 == 0 and W % 64 == 0; executes 1/4 of the direct form's multiply-adds;
+ *       accuracy envelope: <= 2e-5 absolute against the reference network on its own weights (measured 8e-7), <= 1e-5
+ *       relative against a float64 evaluation on white-noise weights -- about 5x the direct form's rounding error),
+ *   1 = Winograd F(2,3) along x (2/3; the default for the other sizes),
+ *   0 = direct implicit GEMM (bit-for-bit an fmaf chain; the one-flag way back for parity runs).
+ * The default comes from the environment variable PNP_DNCNN_WINOGRAD at plan creation (unset or any other value = 5,
+ * falling back to 1 where the image size does not allow it).                                                          */
 int pnp_dncnn_set_winograd(pnp_dncnn_plan* plan, int enable);
 /* raw network: r = net(x), x and r [batch][H][W] fp32 (the predicted noise residual)          */
 int pnp_dncnn_forward(pnp_dncnn_plan* plan, const float* x, float* r, void* stream);

@@ -12,18 +12,28 @@
 // is 128 registers x 512 lanes), the rest is working space -- at 1024 threads (128 VGPRs) the same kernel spilled ~300
 // registers per lane to scratch and the spill traffic alone exceeded the HBM traffic it was meant to save (measured).
 //
-// Phases (all data movement between them is through the CU's LDS):
-//   1  rows forward   : 32 lane-groups x 4 passes; a group packs two real rows of (a - b) into one complex FFT-256
-//                       (fft.h layout: lane + 16 * register)
-//   2  columns        : the 256 KiB raw spectrum does not fit LDS, so it crosses in two halves of 128 k-space columns
-//                       chosen so that kx and W - kx travel together (the split of the packed transforms needs both):
-//                       row side writes [kx][row pair]; every group takes two column pairs, splits each into the true
-//                       half-spectrum column (256 points), FFT -> selector weights (bit-packed mask o minibatch) -> inverse
-//                       FFT in registers, re-packs and writes back; row side reads its entries back
-//   3  rows inverse   : one complex inverse FFT per row pair = two real rows; epilogue alpha*g + beta*c1 + gamma*c2
-//   4  re-layout      : row-pair layout -> the prox's column layout (4 lanes x 64 rows per column; every lane ends up
-//                       with column c and column c + 128), two halves of 128 image columns through LDS
-//   5  prox           : prox_tv.h -- per-column MAD noise estimate, Haar BayesShrink, squared error, store
+// Register layouts of the image (all hand-overs between them go through the CU's LDS, half an image = 128 KB at a time):
+//   R  "rows"    : every lane holds 16-byte pieces of rows -- row pair rp = 16 pass + 2 wave + (lane >> 5), columns
+//                  4 cb .. 4 cb + 3 and 128 + 4 cb .., cb = lane & 31, for the 8 passes.  EVERY global access of the kernel
+//                  is made in this layout: one dwordx4 per lane, a half-wave covering 512 contiguous bytes.  (Round 2 loaded
+//                  and stored in the F and C layouts, four bytes per lane in 64-byte segments: in-kernel clock stamps showed
+//                  53 % of a workgroup's time in those phases at ~10 B/clk/CU -- the quad rate of dword accesses, not HBM.)
+//   F  "FFT"     : fft.h's lane + 16 r layout: lane group g (16 lanes) holds the complex row-pair signal
+//                  Z[p][r] = (row 2 rp, row 2 rp + 1) at column l + 16 r, rp = 32 p + g
+//   C  "columns" : the prox's layout: wave wv owns image columns [16 wv, 16 wv + 16) and 128 + the same; lane = column + 16 q
+//                  keeps rows [64 q, 64 q + 64) of both
+// Phases:
+//   1  operands     : a, b in R, a - b, R -> F
+//   1' rows forward : a group packs two real rows into one complex FFT-256
+//   2  columns      : the 256 KiB raw spectrum does not fit LDS, so it crosses in two halves of 128 k-space columns
+//                     chosen so that kx and W - kx travel together (the split of the packed transforms needs both):
+//                     row side writes [kx][row pair]; every group takes two column pairs, splits each into the true
+//                     half-spectrum column (256 points), FFT -> selector weights (bit-packed mask o minibatch) -> inverse
+//                     FFT in registers, re-packs and writes back; row side reads its entries back
+//   3  rows inverse : one complex inverse FFT per row pair = two real rows; F -> R; epilogue alpha*g + beta*c1 + gamma*c2 in R
+//                     (gradient-only mode stores here)
+//   4  re-layout    : R -> C
+//   5  prox         : prox_tv.h -- per-column MAD noise estimate, Haar BayesShrink; C -> R; squared error, store
 // The FFT scratch of a lane group is private to it and the group lies inside one wavefront, so the in-FFT exchanges need
 // no workgroup barrier (a wavefront's LDS operations complete in order); barriers separate only the phases that hand data
 // between wavefronts.  DENOISE = false stops after the noise estimate and stores the stepped image (the DnCNN prox takes
@@ -53,7 +63,6 @@ constexpr int FG = FT / 16;                               // 32 lane groups
 constexpr int FP = (FN / 2) / FG;                         // 4 row-pair passes per group
 constexpr int F_SCR = 16 * 17;                            // complex elements of one group's FFT scratch
 constexpr int F_RS = 129;                                 // row stride (complex) of the transposition buffer [128 kx][129]
-constexpr int F_CS = 257;                                 // row stride (floats) of the re-layout buffer [128 cols][257]
 constexpr size_t F_LDS_BYTES = (size_t)128 * F_RS * sizeof(cx<float>);   // 132 096 B >= 32 scratches and 128*257*4
 
 // FFT-256 of one lane group (16 lanes x 16 registers, element lane + 16 r, natural order in and out); twiddles from an
@@ -174,21 +183,96 @@ __device__ __forceinline__ void col_store(const cx<float> (&v)[16], cx<float>* l
     }
 }
 
-// phases 1-3: the gradient step; leaves the stepped image in Z (row-pair layout: Z[p][r] = rows 2rp, 2rp+1 at column
-// l + 16 r, rp = p * 32 + g)
-// a, b, c1, c2: THIS image's arrays (wave-uniform pointers -> scalar base + 32-bit lane offset addressing; 64-bit per-lane
-// addresses for five arrays would cost dozens of registers).  No __restrict__ on them: the batches below are ordered by
-// memory clobbers, which the compiler may ignore for loads it knows to be invariant.
+// ---------------------------------------------------------------------------------------------- layouts and crossings
+using f4 = float4;
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+
+// R layout of one lane: RImg[pass][h2][row01] = row 2 rp + row01, columns 4 (cb + 32 h2) .. + 3, rp = 16 pass + 2 wv + u
+struct RLane {
+    int wv, u, cb;
+    unsigned gbase;                                            // element offset of (row 2 (2 wv + u), column 4 cb) in the image
+    __device__ __forceinline__ RLane(int t) : wv(t >> 6), u((t >> 5) & 1), cb(t & 31) { gbase = (unsigned)(2 * wv + u) * 512u + 4u * cb; }
+    __device__ __forceinline__ unsigned goff(int pass, int h2, int row01) const { return gbase + (unsigned)(pass * 8192 + h2 * 128 + row01 * 256); }
+};
+typedef f4 RImg[8][2][2];
+
+// F-side hand-over buffer (half an image = 64 row pairs x 256 complex = 128 KB): element (row pair rp_local, column c) at
+// rp_local * 256 + (c ^ 16 (rp_local & 1)) -- the XOR puts the two lane groups of a half-wave (consecutive row pairs, the same
+// 16 columns) on different halves of the bank row.  In float units the R side addresses 16-byte pieces {x_c, y_c, x_c+1, y_c+1}.
+__device__ __forceinline__ unsigned fbuf_r_addr(const RLane& L, int pass_l, int h2, int s) {      // float index of piece s (columns +2s, +2s+1)
+    const int rp_local = pass_l * 16 + 2 * L.wv + L.u;                                             // parity = u
+    return (unsigned)(rp_local * 512 + 8 * (L.cb ^ (4 * L.u)) + 256 * h2 + 4 * s);
+}
+
+// R -> F for the row pairs [64 H, 64 H + 64): d = the R registers of passes 4 H .. 4 H + 3
+__device__ __forceinline__ void r_to_f_write(const f4 (&d)[4][2][2], float* ldf, const RLane& L) {
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const f4 X = d[pl][h2][0], Y = d[pl][h2][1];
+            st4(ldf + fbuf_r_addr(L, pl, h2, 0), f4{X.x, Y.x, X.y, Y.y});
+            st4(ldf + fbuf_r_addr(L, pl, h2, 1), f4{X.z, Y.z, X.w, Y.w});
+        }
+}
+__device__ __forceinline__ void f_read(cx<float> (&Z)[FP][16], const cx<float>* ldc, int H, int g, int l) {
+    const int sw = 16 * (g & 1);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const cx<float>* rowp = ldc + (pl * 32 + g) * 256 + l;
+        const cx<float>* rE = rowp + sw;
+        const cx<float>* rO = rowp - sw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Z[2 * H + pl][r] = (r & 1) ? rO[16 * r] : rE[16 * r];
+    }
+}
+__device__ __forceinline__ void f_write(const cx<float> (&Z)[FP][16], cx<float>* ldc, int H, int g, int l) {
+    const int sw = 16 * (g & 1);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        cx<float>* rowp = ldc + (pl * 32 + g) * 256 + l;
+        cx<float>* rE = rowp + sw;
+        cx<float>* rO = rowp - sw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ((r & 1) ? rO : rE)[16 * r] = Z[2 * H + pl][r];
+    }
+}
+__device__ __forceinline__ void f_to_r_read(f4 (&d)[4][2][2], const float* ldf, const RLane& L) {
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const f4 q0 = ld4(ldf + fbuf_r_addr(L, pl, h2, 0)), q1 = ld4(ldf + fbuf_r_addr(L, pl, h2, 1));
+            d[pl][h2][0] = f4{q0.x, q0.z, q1.x, q1.z};
+            d[pl][h2][1] = f4{q0.y, q0.w, q1.y, q1.w};
+        }
+}
+
+// C-side hand-over buffer (half the image's columns = 256 rows x 128 floats = 128 KB): element (row, local column c) at
+// row * 128 + (c ^ 16 ((row >> 6) & 1)) -- lanes q and q + 1 of a column (rows 64 apart) land 16 banks apart.
+__device__ __forceinline__ unsigned cbuf_r_addr(const RLane& L, int pass, int row01) {
+    const int row = pass * 32 + 4 * L.wv + 2 * L.u + row01;                                         // (row >> 6) & 1 == (pass >> 1) & 1
+    return (unsigned)(row * 128 + 4 * (((pass >> 1) & 1) ? (L.cb ^ 4) : L.cb));
+}
+__device__ __forceinline__ unsigned cbuf_c_base(int wv, int cl, int q) { return (unsigned)(64 * q * 128 + ((16 * wv + cl) ^ (16 * (q & 1)))); }
+
+// phases 1-3: the gradient step; leaves alpha * g + beta * c1 + gamma * c2 in R (the R layout).
+// a, b, c1, c2: THIS image's arrays (wave-uniform pointers -> scalar base + 32-bit lane offset addressing).  No __restrict__
+// on them: out may alias a and c1, and the batches below are ordered by memory clobbers, which the compiler may ignore for
+// loads it knows to be invariant.
 // OUTER (the outer-loop refresh folded into the first inner iteration, algorithms/pnp_svrg.py:32-57 at j = 0): the
 // scaled transform IS mu = grad_full(z); the epilogue stores it, stores w = z (the operand c1 it has to load anyway) and
-// leaves z + gamma * mu in Z -- what the plain form computes from an all-zero difference z - w plus mu, bit for bit.
-template <int STOP = 0, bool OUTER = false>
-__device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const float* a, const float* b,
+// leaves z + gamma * mu -- what the plain form computes from an all-zero difference z - w plus mu, bit for bit.
+template <bool OUTER = false>
+__device__ __forceinline__ void fused_gradient(RImg& R, const float* a, const float* b,
                                                const uint32_t* __restrict__ bits, const cx<float>* __restrict__ twtab, cx<float>* twl, cx<float>* ldc,
                                                uint32_t (*sbits)[FG][2][16], const cx<float>* __restrict__ yh, float scale, float beta,
                                                const float* c1, float gamma, const float* c2, int g, int l,
                                                float* w_out = nullptr, float* mu_out = nullptr) {
     cx<float>* scr = ldc + g * F_SCR;
+    float* ldf = reinterpret_cast<float*>(ldc);
+    const RLane L((int)threadIdx.x);
     // selector bits of this group's four column pairs (two per half): fetched now, under the operand loads of phase 1 --
     // inside phase 2 their round trip to L2 sat exposed between two workgroup barriers, once per half
 #pragma unroll
@@ -202,46 +286,46 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
         }
     cx<float> twv = {0.f, 0.f};
     if ((int)threadIdx.x < FN) twv = twtab[threadIdx.x];
-    unsigned off[FP];                                       // element offset of (row 2rp, column l); row 2rp+1 is +FN
+    cx<float> Z[FP][16];
+    // ------------------------------------------------------------------ 1: operands in R, a - b, R -> F
+    // Register budget (256 per lane): half an image of each operand is 64 registers; the halves are pinned by memory
+    // clobbers (left to itself the compiler issues all loads of both halves at once and spills).
 #pragma unroll
-    for (int p = 0; p < FP; ++p) off[p] = (unsigned)(2 * (p * FG + g)) * FN + l;
-    // ------------------------------------------------------------------ 1: rows forward
-    // Register budget (256 per lane): the image is 128, one FFT needs ~64 of working space.  So the operands arrive in
-    // batches that never coexist with a transform: `a` of all four row pairs (128 loads in flight per lane), then `b` two
-    // row pairs at a time, then the four transforms.  (Left to itself the compiler issues all 256 loads at once and
-    // spills; the memory clobbers pin the batches.)
+    for (int H = 0; H < 2; ++H) {
+        f4 d[4][2][2];
 #pragma unroll
-    for (int p = 0; p < FP; ++p)
+        for (int pl = 0; pl < 4; ++pl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Z[p][r] = {a[off[p] + 16 * r], a[off[p] + FN + 16 * r]};
-    asm volatile("" ::: "memory");
-    if (b != nullptr) {
+            for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-        for (int p0 = 0; p0 < FP; p0 += 2) {
-            cx<float> tb[2][16];
+                for (int q = 0; q < 2; ++q) d[pl][h2][q] = ld4(a + L.goff(4 * H + pl, h2, q));
+        if (b != nullptr) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int pl = 0; pl < 4; ++pl)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tb[k][r] = {b[off[p0 + k] + 16 * r], b[off[p0 + k] + FN + 16 * r]};
+                for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Z[p0 + k][r] = csub(Z[p0 + k][r], tb[k][r]);
-            asm volatile("" ::: "memory");
+                    for (int q = 0; q < 2; ++q) {
+                        const f4 bv = ld4(b + L.goff(4 * H + pl, h2, q));
+                        f4& dv = d[pl][h2][q];
+                        dv = f4{dv.x - bv.x, dv.y - bv.y, dv.z - bv.z, dv.w - bv.w};
+                    }
         }
+        if (H == 1) __syncthreads();                            // the first half's readers are done with the buffer
+        r_to_f_write(d, ldf, L);
+        if (H == 0 && (int)threadIdx.x < FN) twl[threadIdx.x] = twv;   // twiddles: requested before the operands, landed with them
+        __syncthreads();
+        f_read(Z, ldc, H, g, l);
+        asm volatile("" ::: "memory");
     }
-    // twiddles: requested before the operands (twv above), landed with them; the barrier also orders the selector bits
-    if ((int)threadIdx.x < FN) twl[threadIdx.x] = twv;
-    __syncthreads();
+    __syncthreads();                                            // the buffer becomes FFT scratch; also orders twl and the selector bits
     PNP_STAMP(1);
-    if (STOP == 10) return;                                 // (diagnostic: the operand loads of phase 1 alone)
 #pragma unroll
     for (int p = 0; p < FP; ++p) {
         fft256<false>(Z[p], twl, scr, l);
         asm volatile("" ::: "memory");
     }
     PNP_STAMP(2);
-    if (STOP == 1) return;
 
     // ------------------------------------------------------------------ 2: columns, two halves
 #pragma unroll
@@ -288,10 +372,8 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
     }
     __syncthreads();
     PNP_STAMP(3);
-    if (STOP == 2) return;
 
-    // ------------------------------------------------------------------ 3: rows inverse + epilogue (in place in Z)
-    // same budget: the four inverse transforms first, then the epilogue operands two row pairs at a time
+    // ------------------------------------------------------------------ 3: rows inverse, F -> R, epilogue in R
 #pragma unroll
     for (int p = 0; p < FP; ++p) {
         fft256<true>(Z[p], twl, scr, l);
@@ -302,29 +384,49 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
     for (int p = 0; p < FP; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Z[p][r] = {scale * Z[p][r].x, scale * Z[p][r].y};
+#pragma unroll
+    for (int H = 0; H < 2; ++H) {
+        __syncthreads();                                        // FFT scratch / the first half's readers are done
+        f_write(Z, ldc, H, g, l);
+        __syncthreads();
+        f4 d[4][2][2];
+        f_to_r_read(d, ldf, L);
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) R[4 * H + pl][h2][q] = d[pl][h2][q];
+        asm volatile("" ::: "memory");
+    }
+    // epilogue operands two passes (32 registers per operand) at a time
     if (OUTER) {
 #pragma unroll
-        for (int p0 = 0; p0 < FP; p0 += 2) {
-            cx<float> u[2][16];
+        for (int p0 = 0; p0 < 8; p0 += 2) {
+            f4 u[2][2][2];
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) u[k][r] = {c1[off[p0 + k] + 16 * r], c1[off[p0 + k] + FN + 16 * r]};
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) u[k][h2][q] = ld4(c1 + L.goff(p0 + k, h2, q));
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    mu_out[off[p0 + k] + 16 * r] = Z[p0 + k][r].x;
-                    mu_out[off[p0 + k] + FN + 16 * r] = Z[p0 + k][r].y;
-                }
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) st4(mu_out + L.goff(p0 + k, h2, q), R[p0 + k][h2][q]);
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    w_out[off[p0 + k] + 16 * r] = u[k][r].x;
-                    w_out[off[p0 + k] + FN + 16 * r] = u[k][r].y;
-                    Z[p0 + k][r] = {u[k][r].x + gamma * Z[p0 + k][r].x, u[k][r].y + gamma * Z[p0 + k][r].y};
-                }
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f4 uv = u[k][h2][q];
+                        st4(w_out + L.goff(p0 + k, h2, q), uv);
+                        f4& rv = R[p0 + k][h2][q];
+                        rv = f4{fma_(gamma, rv.x, uv.x), fma_(gamma, rv.y, uv.y), fma_(gamma, rv.z, uv.z), fma_(gamma, rv.w, uv.w)};
+                    }
             asm volatile("" ::: "memory");
         }
         return;
@@ -335,17 +437,24 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
         const float cf = which == 0 ? beta : gamma;
         if (src == nullptr) continue;
 #pragma unroll
-        for (int p0 = 0; p0 < FP; p0 += 2) {
-            cx<float> u[2][16];
+        for (int p0 = 0; p0 < 8; p0 += 4) {
+            f4 u[4][2][2];
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) u[k][r] = {src[off[p0 + k] + 16 * r], src[off[p0 + k] + FN + 16 * r]};
+                for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+                    for (int q = 0; q < 2; ++q) u[k][h2][q] = ld4(src + L.goff(p0 + k, h2, q));
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Z[p0 + k][r] = {Z[p0 + k][r].x + cf * u[k][r].x, Z[p0 + k][r].y + cf * u[k][r].y};
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f4 uv = u[k][h2][q];
+                        f4& rv = R[p0 + k][h2][q];
+                        rv = f4{fma_(cf, uv.x, rv.x), fma_(cf, uv.y, rv.y), fma_(cf, uv.z, rv.z), fma_(cf, uv.w, rv.w)};
+                    }
             asm volatile("" ::: "memory");
         }
     }
@@ -361,12 +470,10 @@ __device__ __forceinline__ void fused_gradient(cx<float> (&Z)[FP][16], const flo
 namespace pnp {
 
 // MODE: 0 = the whole iteration; 1 = stop after the noise estimate and store the stepped image (another prox follows);
-//       2 = the gradient only (phases 1-3, stored in row order: grad_full with its data term, or any other use of
-//           pnp_csmri_grad_sel that fits this kernel).
-// STOP (diagnostic builds, PNP_FUSED_STOP): leave after phase STOP (10 = after the operand loads of phase 1) with a checksum
-// store, to time the phases one by one
+//       2 = the gradient only (phases 1-3: grad_full with its data term, or any other use of pnp_csmri_grad_sel that fits
+//           this kernel).
 enum { FUSED_FULL = 0, FUSED_NO_DENOISE = 1, FUSED_GRAD = 2 };
-template <int MODE, int STOP, bool OUTER = false>
+template <int MODE, bool OUTER = false>
 __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b,
                                                   const uint32_t* __restrict__ bitsT, const cx<float>* __restrict__ yh,
                                                   const cx<float>* __restrict__ twtab,
@@ -390,81 +497,46 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     if (alpha_vec != nullptr) scale *= alpha_vec[prob];
 
     PNP_STAMP(0);
-    cx<float> Z[FP][16];
-    fused_gradient<(STOP == 1 || STOP == 2 || STOP == 10) ? STOP : 0, OUTER>(Z, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
-                   yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
-                   c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l,
-                   OUTER ? w_out + img : nullptr, OUTER ? mu_out + img : nullptr);
+    const RLane L(t);
+    RImg R;
+    fused_gradient<OUTER>(R, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
+                          yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
+                          c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l,
+                          OUTER ? w_out + img : nullptr, OUTER ? mu_out + img : nullptr);
+    float* oi = out + img;
     if (MODE == FUSED_GRAD) {
-        float* oi = out + img;
 #pragma unroll
-        for (int p = 0; p < FP; ++p) {
-            const unsigned o = (unsigned)(2 * (p * FG + g)) * FN + l;
+        for (int pass = 0; pass < 8; ++pass)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { oi[o + 16 * r] = Z[p][r].x; oi[o + FN + 16 * r] = Z[p][r].y; }
-        }
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) st4(oi + L.goff(pass, h2, q), R[pass][h2][q]);
         return;
     }
-    if (STOP == 3 || STOP == 1 || STOP == 2 || STOP == 10) {
-        float acc = 0.f;
-#pragma unroll
-        for (int p = 0; p < FP; ++p)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc += Z[p][r].x + Z[p][r].y;
-        out[img + t] = acc;
-        return;
-    }
-
     PNP_STAMP(5);
-    // ------------------------------------------------------------------ 4: row-pair layout -> column layout
+
+    // ------------------------------------------------------------------ 4: R -> C
     // wave wv owns image columns [16 wv, 16 wv + 16) and [128 + 16 wv, ...); lane = column + 16 * chunk keeps rows
     // [64 chunk, 64 chunk + 64) of both
     float x[2][64];
     const int cl = lane64 & 15, q = lane64 >> 4;
+    const unsigned cbase = cbuf_c_base(wv, cl, q);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int h2 = 0; h2 < 2; ++h2) {
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < FP; ++p)
+        for (int pass = 0; pass < 8; ++pass)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const cx<float> val = Z[p][r + 8 * half];
-                float* dst = ldf + (l + 16 * r) * F_CS + 2 * (p * FG + g);
-                dst[0] = val.x;
-                dst[1] = val.y;
-            }
+            for (int r01 = 0; r01 < 2; ++r01) st4(ldf + cbuf_r_addr(L, pass, r01), R[pass][h2][r01]);
         __syncthreads();
-        const float* src = ldf + (16 * wv + cl) * F_CS + 64 * q;
 #pragma unroll
-        for (int i = 0; i < 64; ++i) x[half][i] = src[i];
+        for (int i = 0; i < 64; ++i) x[h2][i] = ldf[cbase + 128 * i];
     }
-    if (STOP == 4) {
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 64; ++i) acc += x[0][i] + x[1][i];
-        out[img + t] = acc;
-        return;
-    }
+    PNP_STAMP(6);
 
-    // ------------------------------------------------------------------ 5: noise estimate, prox, error, store
-    const unsigned base0 = (unsigned)(q * 64) * FN + 16 * wv + cl, base1 = base0 + 128;   // inside this image
-    float* oi = out + img;
+    // ------------------------------------------------------------------ 5: noise estimate, prox, C -> R, error, store
     const float* xri = xrec != nullptr ? xrec + img : nullptr;
     const bool want_err = DENOISE && xri != nullptr;
-    // The ground truth for the error sum arrives by LDS-DMA while the noise estimate computes (the LDS is idle from here
-    // on): columns [0, 128) of all 256 rows = 128 KiB as [row][128]; one wave instruction moves two rows (1 KiB).
-    auto dma_xrec = [&](int colbase) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int pc = wv + 8 * k;                          // 128 pieces, 16 per wave
-            const float* src = xri + (unsigned)(2 * pc + (lane64 >> 5)) * FN + colbase + 4 * (lane64 & 31);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ldf + pc * 256), 16, 0, 0);
-        }
-    };
-    __syncthreads();                                            // the re-layout reads of every wave are done
-    PNP_STAMP(6);
-    if (want_err) dma_xrec(0);
     // sigma_est = mean over the 256 columns of the per-column MAD estimate
     {
         const float s0 = column_sigma<float, 64>(x[0], q), s1 = column_sigma<float, 64>(x[1], q);
@@ -489,23 +561,38 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     }
     PNP_STAMP(8);
     double err = 0.0;
-    const float* xl = ldf + (64 * q) * 128 + 16 * wv + cl;      // this lane's column in the staged [row][128] block
-    if (want_err) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                        // columns [0, 128) of the ground truth have landed
-        err = (double)column_sq_err<float, 64>(x[0], xl, 128);
-        __syncthreads();
-        dma_xrec(128);                                          // columns [128, 256) under the first half's stores
-    }
 #pragma unroll
-    for (int i = 0; i < 64; ++i) oi[base0 + (unsigned)i * FN] = x[0][i];
-    if (want_err) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        err += (double)column_sq_err<float, 64>(x[1], xl, 128);
-    }
+    for (int h2 = 0; h2 < 2; ++h2) {
+        // the ground truth of this half is requested before the hand-over, so that it arrives under it
+        f4 xr[8][2];
+        if (want_err) {
 #pragma unroll
-    for (int i = 0; i < 64; ++i) oi[base1 + (unsigned)i * FN] = x[1][i];
+            for (int pass = 0; pass < 8; ++pass)
+#pragma unroll
+                for (int r01 = 0; r01 < 2; ++r01) xr[pass][r01] = ld4(xri + L.goff(pass, h2, r01));
+        }
+        __syncthreads();                                        // (h2 == 0: the noise estimate's barriers already passed; kept for symmetry)
+#pragma unroll
+        for (int i = 0; i < 64; ++i) ldf[cbase + 128 * i] = x[h2][i];
+        __syncthreads();
+        float e = 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass)
+#pragma unroll
+            for (int r01 = 0; r01 < 2; ++r01) {
+                const f4 v = ld4(ldf + cbuf_r_addr(L, pass, r01));
+                if (want_err) {
+                    const f4 w4 = xr[pass][r01];
+                    const float d0 = w4.x - v.x, d1 = w4.y - v.y, d2 = w4.z - v.z, d3 = w4.w - v.w;
+                    e += d0 * d0;
+                    e += d1 * d1;
+                    e += d2 * d2;
+                    e += d3 * d3;
+                }
+                st4(oi + L.goff(pass, h2, r01), v);
+            }
+        err += (double)e;
+    }
     if (sse_out != nullptr && want_err) {
         err = wave_sum(err);
         __syncthreads();
@@ -524,49 +611,37 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
 }
 
 // plan internals live in csmri.hip (pnp_csmri_svrg_step / pnp_csmri_grad_sel); the kernel only needs the plan's twiddle table.
-// mode: FUSED_FULL / FUSED_NO_DENOISE / FUSED_GRAD
+// mode: FUSED_FULL / FUSED_NO_DENOISE / FUSED_GRAD; w_out / mu_out != NULL: the outer refresh folded in (pnp_csmri_svrg_outer_step)
 int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* b, const uint32_t* bitsT, const void* yh,
                        double alpha, const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
                        int mode, double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
                        void* stream, void* w_out, void* mu_out) {
     const float scale = (float)(alpha / ((double)FN * (double)FN));
     hipStream_t s = (hipStream_t)stream;
-    const char* stop_env = getenv("PNP_FUSED_STOP");
-    const int stop = stop_env ? atoi(stop_env) : 0;
     // > 64 KiB of dynamic LDS needs the opt-in, once per device (the attribute is per device)
     static unsigned long long attr_done = 0;
     int dev = 0;
     PNP_CHECK_HIP(hipGetDevice(&dev));
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
         attr_done |= 1ull << (dev & 63);
     }
-#define PNP_FUSED_LAUNCH(MD, ST, ...)                                                                                     \
-    k_svrg_iter<MD, ST, ##__VA_ARGS__><<<batch, FT, F_LDS_BYTES, s>>>((const float*)a, (const float*)b, bitsT, (const cx<float>*)yh, \
+#define PNP_FUSED_LAUNCH(...)                                                                                             \
+    k_svrg_iter<__VA_ARGS__><<<batch, FT, F_LDS_BYTES, s>>>((const float*)a, (const float*)b, bitsT, (const cx<float>*)yh,    \
                                                        (const cx<float>*)twtab, scale, (const float*)alpha_vec, (float)beta,    \
                                                        (const float*)c1, (float)gamma, (const float*)c2, (float*)out,         \
                                                        (float)sigma_modifier, (float)fallback_sigma, (const float*)xrec,      \
                                                        sse_out, (float*)sigma_out, (float*)w_out, (float*)mu_out)
     if (w_out != nullptr) {                                     // the outer refresh folded into the first inner iteration
-        if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0, 0, true);
-        else PNP_FUSED_LAUNCH(1, 0, true);
-    } else if (mode == FUSED_GRAD) PNP_FUSED_LAUNCH(2, 0);
-    else if (stop == 1) PNP_FUSED_LAUNCH(0, 1);
-    else if (stop == 2) PNP_FUSED_LAUNCH(0, 2);
-    else if (stop == 10) PNP_FUSED_LAUNCH(0, 10);
-    else if (stop == 3) PNP_FUSED_LAUNCH(0, 3);
-    else if (stop == 4) PNP_FUSED_LAUNCH(0, 4);
-    else if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0, 0);
-    else PNP_FUSED_LAUNCH(1, 0);
+        if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0, true);
+        else PNP_FUSED_LAUNCH(1, true);
+    } else if (mode == FUSED_GRAD) PNP_FUSED_LAUNCH(2);
+    else if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0);
+    else PNP_FUSED_LAUNCH(1);
 #undef PNP_FUSED_LAUNCH
     PNP_CHECK_LAUNCH();
     return PNP_OK;

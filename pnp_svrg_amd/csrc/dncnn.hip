@@ -26,8 +26,6 @@
 //   * per wave and phase: 576 MFMAs (64 cycles each) vs 576 ds_read_b32 + 43 global loads: the
 //     matrix pipe is the only busy resource by a wide margin.
 #include "common.h"
-#include "f16x3.h"
-#include "wino4.h"
 #include "wino44.h"
 #include "tilewalk.h"
 #include "reduce.h"
@@ -460,7 +458,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T* __restrict__ mm,
                                                const float* __restrict__ w, const float* __restrict__ bfirst,
                                                float* __restrict__ out, int H, int W, double srange, double sshift,
-                                               int clamp01, float slope, int a16) {
+                                               int clamp01, float slope) {
     __shared__ float ws[C * 9];
     __shared__ float bs[C];
     for (int i = threadIdx.x; i < C * 9; i += 256) ws[i] = w[i];
@@ -488,32 +486,6 @@ __global__ __launch_bounds__(256) void k_first(const T* __restrict__ z, const T*
             q = (float)u;
         }
         v[t] = q;
-    }
-    if (a16) {
-        // split-fp16 pipeline (dncnn_f16x3.hip): emit the "A16" records directly -- per channel group of 8 one 16-byte
-        // record of high parts fp16(a) and one of low parts fp16(2^11 (a - hi))
-        typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-        h8v* o16 = reinterpret_cast<h8v*>(out);
-        const size_t HW = (size_t)H * W;
-#pragma unroll 1
-        for (int g = 0; g < C / 8; ++g) {
-            h8v hi8, lo8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = 8 * g + j;
-                float a = 0.f;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) a = fmaf(ws[c * 9 + t], v[t], a);
-                a += bs[c];
-                a = a > 0.f ? a : slope * a + 0.f;
-                const _Float16 h = (_Float16)a;
-                hi8[j] = h;
-                lo8[j] = (_Float16)((a - (float)h) * 2048.f);
-            }
-            o16[((size_t)(b * 2 + 0) * 8 + g) * HW + p] = hi8;
-            o16[((size_t)(b * 2 + 1) * 8 + g) * HW + p] = lo8;
-        }
-        return;
     }
 #pragma unroll 4
     for (int c = 0; c < C; ++c) {
@@ -654,9 +626,7 @@ using namespace pnp;
 struct pnp_dncnn_plan {
     int n_mid, H, W, batch, num_cu;
     float *w_first, *w_last, *wpack, *upack, *bias;   // device (upack: Winograd F(2,3)-transformed weights)
-    float* upack4;                               // Winograd F(4,3)-transformed weights (dncnn_wino4.hip)
     float* upack44;                              // Winograd F(4x4,3x3)-transformed weights (dncnn_wino44.hip)
-    void* wpack16;                               // split-fp16 weight fragments (mode 3, dncnn_f16x3.hip)
     float* b_first;                              // [64] device, zeros unless pnp_dncnn_set_affine
     float b_last, slope;                         // last-layer bias, LeakyReLU slope (0 = ReLU)
     int use_wino;
@@ -714,20 +684,14 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
         // along x, 1 = F(2,3) along x, 0 = direct, 3 = opt-in split-fp16
         const char* ev = getenv("PNP_DNCNN_WINOGRAD");
         p->use_wino = ev ? atoi(ev) : 5;
-        if (p->use_wino == 5 && !wino44_supports(H, W)) p->use_wino = 4;
-        if (p->use_wino == 4 && !wino4_supports(H, W)) p->use_wino = 1;
+        if (p->use_wino != 5 && p->use_wino != 1 && p->use_wino != 0) p->use_wino = 5;      // (unknown value: the default)
+        if (p->use_wino == 5 && !wino44_supports(H, W)) p->use_wino = 1;
     }
     const size_t act_bytes = (size_t)batch * C * H * W * sizeof(float);
     hipError_t e = hipMalloc(&p->wpack, pack.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->wpack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->upack, upk.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->upack, upk.data(), upk.size() * sizeof(float), hipMemcpyHostToDevice);
-    {
-        std::vector<float> u4(wino4_weight_floats(n_mid));
-        wino4_pack_weights(w_mid, n_mid, u4.data());
-        if (e == hipSuccess) e = hipMalloc(&p->upack4, u4.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(p->upack4, u4.data(), u4.size() * sizeof(float), hipMemcpyHostToDevice);
-    }
     {
         std::vector<float> u44(wino44_weight_floats(n_mid));
         wino44_pack_weights(w_mid, n_mid, u44.data());
@@ -740,12 +704,6 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e == hipSuccess) e = hipMemcpy(p->w_first, w_first, C * 9 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->w_last, C * 9 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->w_last, w_last, C * 9 * sizeof(float), hipMemcpyHostToDevice);
-    {
-        std::vector<unsigned char> w16(f16x3_weight_bytes(n_mid));
-        f16x3_pack_weights(w_mid, n_mid, w16.data());
-        if (e == hipSuccess) e = hipMalloc(&p->wpack16, w16.size());
-        if (e == hipSuccess) e = hipMemcpy(p->wpack16, w16.data(), w16.size(), hipMemcpyHostToDevice);
-    }
     if (e == hipSuccess) e = hipMalloc(&p->b_first, C * sizeof(float));
     if (e == hipSuccess) e = hipMemset(p->b_first, 0, C * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&p->act0, act_bytes);
@@ -757,7 +715,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e != hipSuccess) {
         set_error(std::string("pnp_dncnn_plan_create: ") + hipGetErrorString(e));
         for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
-                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16, (void*)p->upack4, (void*)p->upack44})
+                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->upack44})
             if (q) (void)hipFree(q);
         delete p;
         return PNP_ERR_HIP;
@@ -769,7 +727,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
 extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
     if (!p) return PNP_OK;
     for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
-                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->wpack16, (void*)p->upack4, (void*)p->upack44})
+                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->upack44})
         (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -790,8 +748,7 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
         sshift = (1.0 - srange) / 2.0;
     }
     dim3 pg(HW / 256, B);
-    k_first<T><<<pg, 256, 0, s>>>(z_in, mm, p->w_first, p->b_first, p->act0, H, W, srange, sshift, mmo ? 1 : 0, p->slope,
-                                  p->use_wino == 3 ? 1 : 0);
+    k_first<T><<<pg, 256, 0, s>>>(z_in, mm, p->w_first, p->b_first, p->act0, H, W, srange, sshift, mmo ? 1 : 0, p->slope);
     PNP_CHECK_LAUNCH();
     const int ntiles = B * (H / TR) * (W / TC);
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
@@ -799,17 +756,9 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     const bool prof = p->profile && p->ev_used + 2 <= p->ev.size();
     if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
     for (int l = 0; l < p->n_mid; ++l) {
-        if (p->use_wino == 3) {
-            const int rc = f16x3_layer(src, dst, (const unsigned char*)p->wpack16 + f16x3_weight_bytes(1) * (size_t)l,
-                                       p->bias + (size_t)l * C, p->zeros, H, W, B, p->num_cu, l == p->n_mid - 1, p->slope, s);
-            if (rc != PNP_OK) return rc;
-        } else if (p->use_wino == 5) {
+        if (p->use_wino == 5) {
             const int rc = wino44_layer(src, dst, p->upack44 + (size_t)l * wino44_weight_floats(1), p->bias + (size_t)l * C, p->zeros,
                                         H, W, B, p->num_cu, p->slope, s);
-            if (rc != PNP_OK) return rc;
-        } else if (p->use_wino == 4) {
-            const int rc = wino4_layer(src, dst, p->upack4 + (size_t)l * wino4_weight_floats(1), p->bias + (size_t)l * C, p->zeros,
-                                       H, W, B, p->num_cu, p->slope, s);
             if (rc != PNP_OK) return rc;
         } else if (p->slope != 0.f) {                             // LeakyReLU builds exist for the two production kernels
             if (p->use_wino)
@@ -852,10 +801,9 @@ extern "C" int pnp_dncnn_set_affine(pnp_dncnn_plan* p, const float* b_first, flo
 
 extern "C" int pnp_dncnn_set_winograd(pnp_dncnn_plan* p, int enable) {
     PNP_CHECK_ARG(p != nullptr, "null plan");
-    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 3 || enable == 4 || enable == 5,
-                  "mode must be 0 (direct), 1 (Winograd F(2,3)), 3 (split-fp16), 4 (Winograd F(4,3)) or 5 (Winograd F(4x4,3x3))");
+    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 5,
+                  "mode must be 0 (direct), 1 (Winograd F(2,3) along x) or 5 (Winograd F(4x4,3x3))");
     PNP_CHECK_ARG(!(enable == 5 && !wino44_supports(p->H, p->W)), "Winograd F(4x4,3x3) needs H % 8 == 0 and W % 64 == 0");
-    PNP_CHECK_ARG(!(enable == 4 && !wino4_supports(p->H, p->W)), "Winograd F(4,3) needs H % 4 == 0 and W % 64 == 0");
     p->use_wino = enable;
     return PNP_OK;
 }
@@ -915,31 +863,6 @@ extern "C" int pnp_dncnn_debug_clock(pnp_dncnn_plan* p, int reps, double* cycles
         std::sort(r5.begin(), r5.end());
         *cycles = c5[g5 / 2];
         *ref_ticks = r5[g5 / 2];
-        return PNP_OK;
-    }
-    if (p->use_wino == 3) {                                     // split-fp16 layer: whole-workgroup cycles and reference ticks
-        // (the activation buffers keep what the last forward pass left in them: realistic operands, realistic power)
-        for (int i = 0; i < reps; ++i) {
-            const int rc = f16x3_layer(p->act0, p->act1, p->wpack16, p->bias, p->zeros, p->H, p->W, p->batch, p->num_cu, 0, 0.f, s,
-                                       i == reps - 1 ? d : nullptr);
-            if (rc != PNP_OK) { (void)hipFree(d); return rc; }
-        }
-        std::vector<unsigned long long> h2((size_t)grid * 5);
-        hipError_t e2 = hipMemcpyAsync(h2.data(), d, h2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
-        if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
-        (void)hipFree(d);
-        PNP_CHECK_HIP(e2);
-        std::vector<double> c2(grid), r2(grid);
-        for (int i = 0; i < grid; ++i) { c2[i] = (double)h2[5 * i]; r2[i] = (double)h2[5 * i + 1]; }
-        if (getenv("PNP_DEBUG_STAMPS")) {
-            double a = 0, b = 0, ep = 0;
-            for (int i = 0; i < grid; ++i) { a += h2[5 * i + 2]; b += h2[5 * i + 3]; ep += h2[5 * i + 4]; }
-            fprintf(stderr, "[k_mid_f16x3 stamps] mean cycles per WG: compute %.0f  barrier %.0f  epilogue %.0f\n", a / grid, b / grid, ep / grid);
-        }
-        std::sort(c2.begin(), c2.end());
-        std::sort(r2.begin(), r2.end());
-        *cycles = c2[grid / 2];
-        *ref_ticks = r2[grid / 2];
         return PNP_OK;
     }
     for (int i = 0; i < reps - 1; ++i) {

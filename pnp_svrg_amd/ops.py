@@ -161,9 +161,8 @@ class DncnnPlan:
 
     def __init__(self, weights, H, W, batch, winograd=None):
         """winograd: 5 = Winograd F(4x4,3x3) conv kernel (default where H % 8 == 0 and W % 64 == 0; fp32, a quarter of the
-        matrix-core work), 4 = Winograd F(4,3) along x (half),
-        True / 1 = F(2,3) (two thirds), False / 0 = direct implicit GEMM (bit-for-bit an fmaf chain), 3 = opt-in
-        split-fp16, None = env PNP_DNCNN_WINOGRAD or the default."""
+        matrix-core work), True / 1 = F(2,3) along x (two thirds; the default elsewhere), False / 0 = direct implicit GEMM
+        (bit-for-bit an fmaf chain), None = env PNP_DNCNN_WINOGRAD or the default."""
         import numpy as np
         require_gpu()
         n = int(weights['n_layers'])

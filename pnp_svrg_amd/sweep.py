@@ -54,6 +54,7 @@ def gather_device(z_local, meta_local, n_items, dst=0, group=None):
     elsewhere.  Single-process: the local data, sorted."""
     meta_local = torch.as_tensor(meta_local, dtype=torch.float64).reshape(z_local.shape[0], -1)
     if not (dist.is_available() and dist.is_initialized()):
+        meta_local = meta_local.cpu()
         order = torch.argsort(meta_local[:, 0])
         return z_local.detach().cpu()[order], meta_local[order]
     world, rank = dist.get_world_size(group), dist.get_rank(group)

@@ -163,6 +163,51 @@ def test_sweep_gloo_world2(tmp_path):
     assert 'SWEEP_OK 18' in out.stdout
 
 
+_WORKER_GATHER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import torch.distributed as dist
+from pnp_svrg_amd import sweep
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+items = sweep.make_items(5, [0.1, 0.2, 0.3], [20.0])            # 15 items on 2 ranks: 8 + 7 (ragged shards)
+mine = sweep.shard(items, rank, world)
+z = torch.stack([torch.full((4, 6), float(it['id'])) for it in mine])
+meta = np.array([[it['id'], 100.0 + it['id']] for it in mine])
+got = sweep.gather_device(z, meta, len(items))
+if rank == 0:
+    zz, mm = got
+    assert zz.shape == (15, 4, 6) and mm.shape == (15, 2)
+    assert mm[:, 0].tolist() == list(range(15)) and mm[:, 1].tolist() == [100.0 + i for i in range(15)]
+    assert all(float(zz[i].min()) == float(zz[i].max()) == i for i in range(15))
+    print('GATHER_OK', zz.shape[0])
+else:
+    assert got is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gather_device_gloo_world2(tmp_path):
+    """The final gather of the sweep as tensor collectives (what `bench.py --workload sweep` times inside its clock; RCCL on
+    the GPU node): ragged round-robin shards of 15 items over 2 ranks arrive complete and in id order on rank 0."""
+    script = tmp_path / 'worker_gather.py'
+    script.write_text(_WORKER_GATHER)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), ROOT],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert 'GATHER_OK 15' in out.stdout
+    # single process: the local rows, sorted by id
+    from pnp_svrg_amd import sweep
+    zz, mm = sweep.gather_device(torch.arange(6.0).reshape(3, 2, 1), np.array([[2, 0.5], [0, 0.25], [1, 0.75]]), 3)
+    assert mm[:, 0].tolist() == [0, 1, 2] and zz[:, 0, 0].tolist() == [2.0, 4.0, 0.0]
+
+
 def test_sweep_csv(tmp_path):
     from pnp_svrg_amd import sweep
     items = sweep.make_items(2, [0.2], [20.0])

@@ -75,29 +75,27 @@ def test_denoise_wrapper(W15, io, g_denoise, dtype):
 
 
 def test_winograd_vs_direct(W15, io):
-    """The four fp32 conv kernels (Winograd F(4x4,3x3) default, F(4,3) and F(2,3) along x, direct fmaf-chain) agree to fp32
+    """The three fp32 conv kernels (Winograd F(4x4,3x3) default, F(2,3) along x, direct fmaf-chain) agree to fp32
     rounding, and all match the reference network."""
     from pnp_svrg_amd import ops
     x = dev(io['net256_in'][None])
     rw = ops.DncnnPlan(W15, 256, 256, 1, winograd=True).forward(x).cpu().numpy()[0]
     rd = ops.DncnnPlan(W15, 256, 256, 1, winograd=False).forward(x).cpu().numpy()[0]
-    r4 = ops.DncnnPlan(W15, 256, 256, 1, winograd=4).forward(x).cpu().numpy()[0]
     r5 = ops.DncnnPlan(W15, 256, 256, 1, winograd=5).forward(x).cpu().numpy()[0]       # F(4x4,3x3): the default
     assert np.array_equal(r5, ops.DncnnPlan(W15, 256, 256, 1).forward(x).cpu().numpy()[0])
-    assert not np.array_equal(rw, rd) and not np.array_equal(r4, rw) and not np.array_equal(r5, r4)   # really four different kernels
-    assert np.abs(rw - rd).max() <= 1e-5 and np.abs(r4 - rd).max() <= 1e-5 and np.abs(r5 - rd).max() <= 1e-5
+    assert not np.array_equal(rw, rd) and not np.array_equal(r5, rw)   # really three different kernels
+    assert np.abs(rw - rd).max() <= 1e-5 and np.abs(r5 - rd).max() <= 1e-5
     assert np.abs(rw - io['net256_out']).max() <= 2e-5 and np.abs(rd - io['net256_out']).max() <= 2e-5
-    assert np.abs(r4 - io['net256_out']).max() <= 2e-5 and np.abs(r5 - io['net256_out']).max() <= 2e-5
-    print('max |conv kernel - reference net|: F(4x4,3x3) %.2e  F(4,3) %.2e  F(2,3) %.2e  direct %.2e' % (
-        np.abs(r5 - io['net256_out']).max(), np.abs(r4 - io['net256_out']).max(), np.abs(rw - io['net256_out']).max(),
-        np.abs(rd - io['net256_out']).max()))
+    assert np.abs(r5 - io['net256_out']).max() <= 2e-5
+    print('max |conv kernel - reference net|: F(4x4,3x3) %.2e  F(2,3) %.2e  direct %.2e' % (
+        np.abs(r5 - io['net256_out']).max(), np.abs(rw - io['net256_out']).max(), np.abs(rd - io['net256_out']).max()))
     # several tiles per persistent workgroup in the XCD-aware order (tilewalk.h), and a count that does not divide
     # (plain walk): every image of a batch must equal its single-image result, for all conv kernels
     rng = np.random.default_rng(5)
     for B in (6, 5):
         xb = rng.random((B, 256, 256)).astype(np.float32)
         xb[B - 1] = io['net256_in']
-        for mode in (5, 4, 1, 0):
+        for mode in (5, 1, 0):
             rb = ops.DncnnPlan(W15, 256, 256, B, winograd=mode).forward(dev(xb)).cpu().numpy()
             one = ops.DncnnPlan(W15, 256, 256, 1, winograd=mode).forward(dev(xb[1:2])).cpu().numpy()[0]
             assert np.array_equal(rb[1], one), (B, mode)
@@ -160,7 +158,7 @@ def test_simplecnn_family(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('winograd', [True, False, 3, 4, 5])
+@pytest.mark.parametrize('winograd', [True, False, 5])
 def test_mmo_denoiser_vs_reference(winograd):
     """SURVEY 8(f) n3: MMODenoiser (20-layer bias / LeakyReLU(0.01) / skip net, transposed input, both clamps;
     reference denoisers/MMODenoise.py:18-40,73-128) through the MFMA conv stack vs the reference's own classes
@@ -174,7 +172,7 @@ def test_mmo_denoiser_vs_reference(winograd):
         sd['module.' + n + '.weight'] = torch.from_numpy(g[f'conv{i}.weight'])
         sd['module.' + n + '.bias'] = torch.from_numpy(g[f'conv{i}.bias'])
     old = os.environ.get('PNP_DNCNN_WINOGRAD')
-    os.environ['PNP_DNCNN_WINOGRAD'] = str(int(winograd))     # 5 / 4 / 1 = Winograd kernels (LeakyReLU builds), 0 = direct, 3 = split-fp16
+    os.environ['PNP_DNCNN_WINOGRAD'] = str(int(winograd))     # 5 / 1 = Winograd kernels (LeakyReLU builds), 0 = direct
     try:
         den = MMODenoiser(model=sd, channels=1)
         for name in ('sq', 'rect'):
@@ -215,43 +213,10 @@ def test_mmo_device_batch_and_sse():
     assert np.allclose(sse.cpu().numpy(), ref, rtol=1e-10, atol=1e-12)
 
 
-def test_split_fp16_conv_mode(W15, io):
-    """Opt-in mode 3 (dncnn_f16x3.hip): every fp32 operand split into two fp16 terms, three fp16 MFMAs per product
-    with fp32 accumulation.  Bounds its deviation (a) from the reference network's own output with the same 2e-5
-    bound the fp32 kernels meet, (b) from the direct fp32 kernel, on square, rectangular and batched inputs; and the
-    whole denoise() wrapper."""
-    from pnp_svrg_amd import ops
-    for n in (64, 256):
-        x = dev(io[f'net{n}_in'][None])
-        r3 = ops.DncnnPlan(W15, n, n, 1, winograd=3).forward(x).cpu().numpy()[0]
-        r0 = ops.DncnnPlan(W15, n, n, 1, winograd=0).forward(x).cpu().numpy()[0]
-        ref = io[f'net{n}_out']
-        e_ref, e_f32 = np.abs(r3 - ref).max(), np.abs(r3 - r0).max()
-        print(f'split-fp16 {n}x{n}: max |.-reference| {e_ref:.2e} (fp32 direct kernel: {np.abs(r0 - ref).max():.2e}), max |.-fp32 kernel| {e_f32:.2e}')
-        assert e_ref <= 2e-5 and e_f32 <= 2e-5
-    rng = np.random.default_rng(1)
-    xb = rng.random((3, 40, 96)).astype(np.float32)
-    r3 = ops.DncnnPlan(W15, 40, 96, 3, winograd=3).forward(dev(xb)).cpu().numpy()
-    for i in range(3):
-        assert np.abs(r3[i] - od.dncnn_forward(W15, xb[i])).max() <= 2e-5
-    # a grid of several tiles per CU (the persistent walk, XCD-aware order): 4 different 256 x 256 images
-    x4 = rng.random((4, 256, 256)).astype(np.float32)
-    x4[0] = io['net256_in']
-    r3 = ops.DncnnPlan(W15, 256, 256, 4, winograd=3).forward(dev(x4)).cpu().numpy()
-    r0 = ops.DncnnPlan(W15, 256, 256, 4, winograd=0).forward(dev(x4)).cpu().numpy()
-    assert np.abs(r3[0] - io['net256_out']).max() <= 2e-5 and np.abs(r3 - r0).max() <= 2e-5
-    z = dev(io['net64_in'][None] * 0.8 + 0.1, torch.float64)
-    a, _ = ops.DncnnPlan(W15, 64, 64, 1, winograd=3).denoise(z, 15.0)
-    b, _ = ops.DncnnPlan(W15, 64, 64, 1, winograd=0).denoise(z, 15.0)
-    assert (a - b).abs().max().item() <= 2e-5
-
-
 @pytest.mark.parametrize('scale', [1.0, 1e-3, 50.0])
 def test_conv_kernels_against_float64(scale):
     """Error of each conv kernel against a float64 evaluation of the same 3-layer net (1->64, 64->64 + bias + ReLU,
-    64->1; random weights), at activation scales from 1e-3 to 50: the opt-in split-fp16 kernel stays within 2x the
-    error of the plain fp32 kernels (it is an fp32-class evaluation, not a reduced-precision one), fp16 range
-    permitting (|activation| < 65504)."""
+    64->1; random weights), at activation scales from 1e-3 to 50."""
     import torch.nn.functional as F
     from pnp_svrg_amd import ops
     rng = np.random.default_rng(11)
@@ -267,12 +232,10 @@ def test_conv_kernels_against_float64(scale):
     t = F.relu(F.conv2d(t, torch.from_numpy(w['conv1.weight']).double(), torch.from_numpy(w['conv1.bias']).double(), padding=1))
     ref = F.conv2d(t, torch.from_numpy(w['conv2.weight']).double(), padding=1)[:, 0].numpy()
     err = {}
-    for mode in (0, 1, 3, 4, 5):
+    for mode in (0, 1, 5):
         r = ops.DncnnPlan(w, n, n, 2, winograd=mode).forward(dev(x)).cpu().numpy().astype(np.float64)
         err[mode] = np.abs(r - ref).max() / np.abs(ref).max()
-    print(f'scale {scale}: relative max error vs float64 -- fp32 direct {err[0]:.2e}, F(2,3) {err[1]:.2e}, F(4,3) {err[4]:.2e}, '
-          f'F(4x4,3x3) {err[5]:.2e}, split-fp16 {err[3]:.2e}')
+    print(f'scale {scale}: relative max error vs float64 -- fp32 direct {err[0]:.2e}, F(2,3) {err[1]:.2e}, F(4x4,3x3) {err[5]:.2e}')
     # the two-dimensional transform pays for its 4x fewer multiply-adds with ~4-5x the rounding error of the direct form on
     # white-noise weights (transform entries up to 8 and 1/24); on the reference's weights: 8e-7 vs 4e-7 (test_winograd_vs_direct)
-    assert err[0] < 2e-6 and err[1] < 2e-6 and err[4] < 2e-6 and err[5] < 1e-5
-    assert err[3] < 2 * max(err[0], err[1]) + 1e-7
+    assert err[0] < 2e-6 and err[1] < 2e-6 and err[5] < 1e-5

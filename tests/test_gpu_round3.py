@@ -232,3 +232,39 @@ def test_sweep_runner_cells_and_hist_size_grid(tmp_path):
     sweep.write_tuning_csv(str(tmp_path / 't.csv'), rows, problem='DeblurSR', denoiser='TV', algorithm='pnp_saga')
     txt = (tmp_path / 't.csv').read_text().splitlines()
     assert txt[0] == 'Results:' and txt[1].startswith('DeblurSR,TV,pnp_saga,1.0,20.0,') and ',PARAMETERS:,eta,' in txt[1] and ',hist_size,' in txt[1]
+
+
+# ------------------------------------------------------------------------------------------------ config 5 bench path
+def test_bench_sweep_workload_one_gpu():
+    """`bench.py --workload sweep` (BASELINE config 5: 120 work items through `sweep` with the gather inside the clock) on one
+    GPU: contract fields, strong scaling, every item gathered, PSNR improved."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'sweep', '--steps', '10', '--warmup', '1',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['scaling'] == 'strong' and line['n_gpus'] == 1 and line['unit'] == 'item-inner-iters/s'
+    assert line['config']['items_total'] == 120 and line['psnr_db']['items_gathered'] == 120
+    assert line['warmup'] == 10 and line['steps'] == 10               # whole outer iterations (hipGraph replays)
+    assert abs(line['value'] - 120 * 10 / (line['ms_per_step'] * 10 / 1e3)) < 1e-2 * line['value']
+    assert 0 < line['roofline']['frac'] < 1 and line['psnr_db']['after_timed_steps_mean'] > 15
+
+
+def test_bench_sweep_two_ranks_rehearsal():
+    """The N > 1 path of the sweep workload (items dealt round-robin, one batch per rank, tensor gather inside the clock, MAX
+    over ranks) with 2 ranks sharing GPU 0 over gloo (RCCL needs one GPU per rank; the driver runs the real N = 2/4/8)."""
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PNP_BENCH_ONE_DEVICE='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+                          '--gpus', '2', '--workload', 'sweep', '--steps', '10', '--warmup', '10', '--backend', 'gloo',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['items_per_gpu'] == 60
+    assert line['psnr_db']['items_gathered'] == 120 and line['value'] > 0

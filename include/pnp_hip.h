@@ -252,6 +252,15 @@ int pnp_dncnn_profile_end(pnp_dncnn_plan* plan, double* avg_ms_per_launch, long*
 /* Diagnostic (allocates + synchronises; never on the hot path): median in-kernel shader cycles and 100 MHz
  * reference ticks of the conv tile loop after `reps` back-to-back launches -> the clock held under load. */
 int pnp_dncnn_debug_clock(pnp_dncnn_plan* plan, int reps, double* cycles, double* ref_ticks, void* stream);
+/* Test hooks (never on the hot path): ONE 64->64 layer of the plan's network, kernel as selected by pnp_dncnn_set_winograd, on
+ * CALLER-provided activation buffers in/out [batch][64][H][W] fp32 -- so that a test can put guard bands around them
+ * (tests/test_gpu_dncnn.py::test_wino44_guard_bands).  w44_override (may be NULL; mode 5 only): packed F(4x4,3x3) weights of
+ * the layer in the caller's memory, pnp_dncnn_debug_w44_floats() floats as pnp_dncnn_debug_w44_weights copies them out.
+ * w44_rows: 0 = the production choice of region form, 1 / 2 = 4 x 64 / 8 x 64 regions for the whole layer (mode 5 only).        */
+size_t pnp_dncnn_debug_w44_floats(void);
+int pnp_dncnn_debug_w44_weights(pnp_dncnn_plan* plan, int layer, float* dst, void* stream);
+int pnp_dncnn_debug_mid_layer(pnp_dncnn_plan* plan, int layer, const float* in, float* out, const float* w44_override,
+                              int w44_rows, void* stream);
 
 /* Device-resident step counter and log ring (hipGraph replay of a whole outer iteration: nothing in the graph
  * depends on a host-side step index).  pnp_log_append: log[(*step_dev % n_log)][0..n) = src[0..n).        */

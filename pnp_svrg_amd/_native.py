@@ -59,6 +59,9 @@ SIGNATURES = {
     'pnp_dncnn_profile_begin': (_i, [_vp, _i]),
     'pnp_dncnn_profile_end': (_i, [_vp, ctypes.POINTER(_d), ctypes.POINTER(ctypes.c_long)]),
     'pnp_dncnn_debug_clock': (_i, [_vp, _i, ctypes.POINTER(_d), ctypes.POINTER(_d), _vp]),
+    'pnp_dncnn_debug_w44_floats': (_sz, []),
+    'pnp_dncnn_debug_w44_weights': (_i, [_vp, _i, _vp, _vp]),
+    'pnp_dncnn_debug_mid_layer': (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     'pnp_draw_thresholds': (_i, [_i, _i, _i, ctypes.c_uint64, ctypes.c_uint32, _i, _vp, _vp, _vp]),
     'pnp_indicator_from_thresholds': (_i, [_i, _i, _vp, _vp, _vp]),
     'pnp_rows_from_thresholds': (_i, [_i, _i, _i, _vp, _vp, _vp]),

@@ -39,6 +39,7 @@
 // between wavefronts.  DENOISE = false stops after the noise estimate and stores the stepped image (the DnCNN prox takes
 // over from there).
 #include "fft.h"
+#include <type_traits>
 #include <cstdlib>
 
 // Diagnostic build (-DPNP_FUSED_CLOCK, tools/fused_clock.py): thread 0 of every workgroup stamps the shader clock at the phase
@@ -47,12 +48,24 @@
 #ifdef PNP_FUSED_CLOCK
 #define PNP_STAMP_MAXB 4096
 __device__ unsigned long long g_fused_stamps[PNP_STAMP_MAXB * 16];
-#define PNP_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < PNP_STAMP_MAXB) g_fused_stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+// the stamps stay in scalar registers until the end of the kernel (stamping through memory raised the vector-register pressure
+// enough for hipcc to spill a ground-truth load that was still in flight -- tools/check_fused_isa.py -DPNP_FUSED_CLOCK)
+#define PNP_STAMP_DECL unsigned long long stamp_[16] = {0}
+#define PNP_STAMP_PARAM , unsigned long long (&stamp_)[16]
+#define PNP_STAMP_ARG , stamp_
+#define PNP_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp_[k] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
+#define PNP_STAMP_NW(k) do { asm volatile("" ::: "memory"); stamp_[k] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
+#define PNP_STAMP_FLUSH do { if (threadIdx.x == 0 && blockIdx.x < PNP_STAMP_MAXB) { _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) g_fused_stamps[blockIdx.x * 16 + k_] = stamp_[k_]; } } while (0)
 extern "C" int pnp_debug_fused_stamps(unsigned long long* host_out, int nblocks) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_stamps), (size_t)nblocks * 16 * sizeof(unsigned long long));
 }
 #else
+#define PNP_STAMP_DECL
+#define PNP_STAMP_PARAM
+#define PNP_STAMP_ARG
 #define PNP_STAMP(k) do { } while (0)
+#define PNP_STAMP_NW(k) do { } while (0)
+#define PNP_STAMP_FLUSH do { } while (0)
 #endif
 
 namespace pnp {
@@ -184,15 +197,67 @@ __device__ __forceinline__ void col_store(const cx<float> (&v)[16], cx<float>* l
 }
 
 // ---------------------------------------------------------------------------------------------- layouts and crossings
-using f4 = float4;
+typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+
+// Global accesses in the R layout are HAND-ISSUED (inline asm, as the LDS-DMA of the conv kernel): left to hipcc, the 16-byte
+// loads of an operand batch were serialised against the next batch (it re-used their destination registers and waited), and
+// under register pressure every ground-truth load was followed by `s_waitcnt vmcnt(0)` and a spill -- the phases ran at the
+// old 4-byte rate.  Issued by hand, a batch goes out back to back, the next one is requested before the current one is
+// consumed, and ONE counted wait stands in front of each use:
+//   * address = wave-uniform base (scalar register pair) + the lane's 32-bit byte offset + immediate;
+//   * hipcc knows nothing of the loads in flight: gwait() is `s_waitcnt vmcnt(N)` followed by an empty asm that re-defines the
+//     batch's registers, so no use can be scheduled above the wait.  N = the number of hand-issued vector-memory operations
+//     issued AFTER the batch (operations leave the queue in issue order; whatever else hipcc has in the queue -- scratch
+//     traffic -- only makes the wait longer, never shorter);
+//   * a destination register must not be read (or spilled) between its load and its wait: tools/check_fused_isa.py verifies
+//     that on the generated code (CPU test test_fused_loads_untouched).
+template <int IMM> __device__ __forceinline__ void gld(f4& dst, const float* sbase, unsigned voff) {
+    // (s_nop 4: hipcc may have moved the uniform base into its scalar registers with a v_readfirstlane right in front of this
+    //  statement -- a VALU write of an SGPR needs 5 wait states before a VMEM instruction reads it, and the hazard recognizer
+    //  does not pad in front of inline asm; a diagnostic build died of exactly that with an address beyond the aperture)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3 ; PNP_GLD" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+// (a store of more than 64 bits must not be followed directly by a write of its data registers: hipcc's hazard recognizer pads
+//  its own stores, but does not look inside inline asm -- without the s_nop the next piece's v_movs, which re-use the same
+//  four registers, corrupted the data in flight)
+template <int IMM> __device__ __forceinline__ void gst(float* sbase, unsigned voff, f4 v) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+// the four pieces (column half h2, row of the pair) of NP passes from pass p0 on: [k][h2][row01]
+template <int NP> __device__ __forceinline__ void gld_passes(f4 (&d)[NP][2][2], const float* img, int p0, unsigned voff) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const float* sb = img + (p0 + k) * 8192;
+        gld<0>(d[k][0][0], sb, voff);
+        gld<1024>(d[k][0][1], sb, voff);
+        gld<512>(d[k][1][0], sb, voff);
+        gld<1536>(d[k][1][1], sb, voff);
+    }
+}
+template <int NP> __device__ __forceinline__ void gst_passes(float* img, int p0, unsigned voff, const f4 (&d)[NP][2][2]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        float* sb = img + (p0 + k) * 8192;
+        gst<0>(sb, voff, d[k][0][0]);
+        gst<1024>(sb, voff, d[k][0][1]);
+        gst<512>(sb, voff, d[k][1][0]);
+        gst<1536>(sb, voff, d[k][1][1]);
+    }
+}
+template <int N, int NP> __device__ __forceinline__ void gwait(f4 (&d)[NP][2][2]) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+#pragma unroll
+    for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(d[k][0][0]), "+v"(d[k][0][1]), "+v"(d[k][1][0]), "+v"(d[k][1][1]));
+}
 
 // R layout of one lane: RImg[pass][h2][row01] = row 2 rp + row01, columns 4 (cb + 32 h2) .. + 3, rp = 16 pass + 2 wv + u
 struct RLane {
     int wv, u, cb;
     unsigned gbase;                                            // element offset of (row 2 (2 wv + u), column 4 cb) in the image
-    __device__ __forceinline__ RLane(int t) : wv(t >> 6), u((t >> 5) & 1), cb(t & 31) { gbase = (unsigned)(2 * wv + u) * 512u + 4u * cb; }
+    unsigned voff;                                             // the same in bytes (the lane part of a hand-issued access)
+    __device__ __forceinline__ RLane(int t) : wv(t >> 6), u((t >> 5) & 1), cb(t & 31) { gbase = (unsigned)(2 * wv + u) * 512u + 4u * cb; voff = 4u * gbase; }
     __device__ __forceinline__ unsigned goff(int pass, int h2, int row01) const { return gbase + (unsigned)(pass * 8192 + h2 * 128 + row01 * 256); }
 };
 typedef f4 RImg[8][2][2];
@@ -264,12 +329,15 @@ __device__ __forceinline__ unsigned cbuf_c_base(int wv, int cl, int q) { return 
 // OUTER (the outer-loop refresh folded into the first inner iteration, algorithms/pnp_svrg.py:32-57 at j = 0): the
 // scaled transform IS mu = grad_full(z); the epilogue stores it, stores w = z (the operand c1 it has to load anyway) and
 // leaves z + gamma * mu -- what the plain form computes from an all-zero difference z - w plus mu, bit for bit.
-template <bool OUTER = false>
+// NOPS: epilogue operand arrays actually present (0, 1: c1 with coefficient beta, 2: c1 and c2) -- known at launch, so the
+// epilogue is straight-line code (with run-time tests hipcc kept both prefetch buffers alive everywhere and spilled them while
+// their loads were in flight)
+template <bool OUTER = false, int NOPS = 2>
 __device__ __forceinline__ void fused_gradient(RImg& R, const float* a, const float* b,
                                                const uint32_t* __restrict__ bits, const cx<float>* __restrict__ twtab, cx<float>* twl, cx<float>* ldc,
                                                uint32_t (*sbits)[FG][2][16], const cx<float>* __restrict__ yh, float scale, float beta,
                                                const float* c1, float gamma, const float* c2, int g, int l,
-                                               float* w_out = nullptr, float* mu_out = nullptr) {
+                                               float* w_out, float* mu_out PNP_STAMP_PARAM) {
     cx<float>* scr = ldc + g * F_SCR;
     float* ldf = reinterpret_cast<float*>(ldc);
     const RLane L((int)threadIdx.x);
@@ -288,35 +356,35 @@ __device__ __forceinline__ void fused_gradient(RImg& R, const float* a, const fl
     if ((int)threadIdx.x < FN) twv = twtab[threadIdx.x];
     cx<float> Z[FP][16];
     // ------------------------------------------------------------------ 1: operands in R, a - b, R -> F
-    // Register budget (256 per lane): half an image of each operand is 64 registers; the halves are pinned by memory
-    // clobbers (left to itself the compiler issues all loads of both halves at once and spills).
+    // Register budget (256 per lane): half an image of each operand is 64 registers.  Both operands of a half are requested
+    // back to back; the second half's `a` goes out before the first half's hand-over, its `b` after it.
+    {
+        f4 A[4][2][2], Bv[4][2][2];
+        gld_passes<4>(A, a, 0, L.voff);
+        if (b != nullptr) gld_passes<4>(Bv, b, 0, L.voff);
 #pragma unroll
-    for (int H = 0; H < 2; ++H) {
-        f4 d[4][2][2];
+        for (int H = 0; H < 2; ++H) {
+            gwait<0, 4>(A);
+            if (b != nullptr) {
+                gwait<0, 4>(Bv);
 #pragma unroll
-        for (int pl = 0; pl < 4; ++pl)
+                for (int pl = 0; pl < 4; ++pl)
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
+                    for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) d[pl][h2][q] = ld4(a + L.goff(4 * H + pl, h2, q));
-        if (b != nullptr) {
-#pragma unroll
-            for (int pl = 0; pl < 4; ++pl)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const f4 bv = ld4(b + L.goff(4 * H + pl, h2, q));
-                        f4& dv = d[pl][h2][q];
-                        dv = f4{dv.x - bv.x, dv.y - bv.y, dv.z - bv.z, dv.w - bv.w};
-                    }
+                        for (int q = 0; q < 2; ++q) A[pl][h2][q] -= Bv[pl][h2][q];
+            }
+            if (H == 1) __syncthreads();                        // the first half's readers are done with the buffer
+            r_to_f_write(A, ldf, L);
+            if (H == 0) {
+                if ((int)threadIdx.x < FN) twl[threadIdx.x] = twv;   // twiddles: requested before the operands, landed with them
+                gld_passes<4>(A, a, 4, L.voff);
+                if (b != nullptr) gld_passes<4>(Bv, b, 4, L.voff);
+            }
+            __syncthreads();
+            f_read(Z, ldc, H, g, l);
+            asm volatile("" ::: "memory");
         }
-        if (H == 1) __syncthreads();                            // the first half's readers are done with the buffer
-        r_to_f_write(d, ldf, L);
-        if (H == 0 && (int)threadIdx.x < FN) twl[threadIdx.x] = twv;   // twiddles: requested before the operands, landed with them
-        __syncthreads();
-        f_read(Z, ldc, H, g, l);
-        asm volatile("" ::: "memory");
     }
     __syncthreads();                                            // the buffer becomes FFT scratch; also orders twl and the selector bits
     PNP_STAMP(1);
@@ -384,6 +452,14 @@ __device__ __forceinline__ void fused_gradient(RImg& R, const float* a, const fl
     for (int p = 0; p < FP; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Z[p][r] = {scale * Z[p][r].x, scale * Z[p][r].y};
+    // epilogue operands: batches of two passes (8 pieces = 32 registers), two batches in flight.  With the refresh folded in
+    // the first two are requested here, so that they arrive under the F -> R hand-over (the plain form has no registers to
+    // spare across the hand-over: it requests them behind it)
+    f4 U[2][2][2][2];                                           // [buffer][pass of the batch][h2][row01]
+    if (OUTER) {
+        gld_passes<2>(U[0], c1, 0, L.voff);
+        gld_passes<2>(U[1], c1, 2, L.voff);
+    }
 #pragma unroll
     for (int H = 0; H < 2; ++H) {
         __syncthreads();                                        // FFT scratch / the first half's readers are done
@@ -399,63 +475,78 @@ __device__ __forceinline__ void fused_gradient(RImg& R, const float* a, const fl
                 for (int q = 0; q < 2; ++q) R[4 * H + pl][h2][q] = d[pl][h2][q];
         asm volatile("" ::: "memory");
     }
-    // epilogue operands two passes (32 registers per operand) at a time
     if (OUTER) {
+        // batch k: passes 2k, 2k + 1.  mu = R (stored), w = c1 (stored), R <- c1 + gamma * mu
 #pragma unroll
-        for (int p0 = 0; p0 < 8; p0 += 2) {
-            f4 u[2][2][2];
+        for (int k = 0; k < 4; ++k) {
+            // operations issued after batch k's loads: batch k + 1's 8 loads; and for k >= 1 the 16 stores of step k - 1, which
+            // went out between the loads of batch k + 1 ... (see the order below: loads of k + 2 are issued at the end of step k)
+            if (k == 0) gwait<8, 2>(U[0]);
+            else if (k < 3) gwait<8, 2>(U[k & 1]);               // queue behind batch k: [16 stores of step k - 1 are OLDER] batch k + 1
+            else gwait<0, 2>(U[k & 1]);
+            f4 mu2[2][2][2];
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) u[k][h2][q] = ld4(c1 + L.goff(p0 + k, h2, q));
+                    for (int q = 0; q < 2; ++q) mu2[j][h2][q] = R[2 * k + j][h2][q];
+            gst_passes<2>(mu_out, 2 * k, L.voff, mu2);
+            gst_passes<2>(w_out, 2 * k, L.voff, U[k & 1]);
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) st4(mu_out + L.goff(p0 + k, h2, q), R[p0 + k][h2][q]);
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const f4 uv = u[k][h2][q];
-                        st4(w_out + L.goff(p0 + k, h2, q), uv);
-                        f4& rv = R[p0 + k][h2][q];
+                        const f4 uv = U[k & 1][j][h2][q];
+                        f4& rv = R[2 * k + j][h2][q];
                         rv = f4{fma_(gamma, rv.x, uv.x), fma_(gamma, rv.y, uv.y), fma_(gamma, rv.z, uv.z), fma_(gamma, rv.w, uv.w)};
                     }
-            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                asm volatile("" : "+v"(R[2 * k + j][0][0]), "+v"(R[2 * k + j][0][1]), "+v"(R[2 * k + j][1][0]), "+v"(R[2 * k + j][1][1]));
+            if (k + 2 < 4) gld_passes<2>(U[k & 1], c1, 2 * (k + 2), L.voff);
         }
         return;
     }
+    if constexpr (NOPS > 0) {
+        gld_passes<2>(U[0], c1, 0, L.voff);
+        gld_passes<2>(U[1], c1, 2, L.voff);
+        // one operand array = four batches; on entry its batches 0 and 1 are in flight; NEXT: another array follows (its first
+        // two batches are requested from here, so that they are in flight when its turn comes)
+        auto stage = [&](const float* src, float cf, auto NEXT, const float* nxt) {
+            constexpr bool HAS_NEXT = decltype(NEXT)::value;
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        const float* src = which == 0 ? c1 : c2;
-        const float cf = which == 0 ? beta : gamma;
-        if (src == nullptr) continue;
+            for (int k = 0; k < 4; ++k) {
+                // behind batch k in the queue: batch k + 1 (8 loads) when there is one
+                if (k < 3 || HAS_NEXT) gwait<8, 2>(U[k & 1]);
+                else gwait<0, 2>(U[k & 1]);
 #pragma unroll
-        for (int p0 = 0; p0 < 8; p0 += 4) {
-            f4 u[4][2][2];
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+                    for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
+                        for (int q = 0; q < 2; ++q) {
+                            const f4 uv = U[k & 1][j][h2][q];
+                            f4& rv = R[2 * k + j][h2][q];
+                            rv = f4{fma_(cf, uv.x, rv.x), fma_(cf, uv.y, rv.y), fma_(cf, uv.z, rv.z), fma_(cf, uv.w, rv.w)};
+                        }
+                // the batch is consumed before its buffer is requested again: an empty asm takes the results, and the requests
+                // (volatile asm as well) cannot pass it -- left alone hipcc defers the arithmetic, keeps every batch in
+                // registers of its own and spills
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) u[k][h2][q] = ld4(src + L.goff(p0 + k, h2, q));
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const f4 uv = u[k][h2][q];
-                        f4& rv = R[p0 + k][h2][q];
-                        rv = f4{fma_(cf, uv.x, rv.x), fma_(cf, uv.y, rv.y), fma_(cf, uv.z, rv.z), fma_(cf, uv.w, rv.w)};
-                    }
-            asm volatile("" ::: "memory");
+                for (int j = 0; j < 2; ++j)
+                    asm volatile("" : "+v"(R[2 * k + j][0][0]), "+v"(R[2 * k + j][0][1]), "+v"(R[2 * k + j][1][0]), "+v"(R[2 * k + j][1][1]));
+                if (k + 2 < 4) gld_passes<2>(U[k & 1], src, 2 * (k + 2), L.voff);
+                else if (HAS_NEXT) gld_passes<2>(U[k & 1], nxt, 2 * (k - 2), L.voff);
+            }
+        };
+        if constexpr (NOPS == 2) {
+            stage(c1, beta, std::true_type{}, c2);
+            stage(c2, gamma, std::false_type{}, nullptr);
+        } else {
+            stage(c1, beta, std::false_type{}, nullptr);
         }
     }
 }
@@ -473,7 +564,7 @@ namespace pnp {
 //       2 = the gradient only (phases 1-3: grad_full with its data term, or any other use of pnp_csmri_grad_sel that fits
 //           this kernel).
 enum { FUSED_FULL = 0, FUSED_NO_DENOISE = 1, FUSED_GRAD = 2 };
-template <int MODE, bool OUTER = false>
+template <int MODE, bool OUTER = false, int NOPS = 2>
 __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b,
                                                   const uint32_t* __restrict__ bitsT, const cx<float>* __restrict__ yh,
                                                   const cx<float>* __restrict__ twtab,
@@ -481,8 +572,18 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
                                                   float gamma, const float* c2, float* out,
                                                   float sigma_modifier, float fallback_sigma, const float* __restrict__ xrec,
                                                   double* __restrict__ sse_out, float* __restrict__ sigma_out,
-                                                  float* w_out, float* mu_out) {
+                                                  float* w_out, float* mu_out, int stagger_n, int stagger_groups, int stagger_units) {
     constexpr bool DENOISE = MODE == FUSED_FULL;
+    // De-synchronisation of the CUs.  Every workgroup does the same work, so the 256 CUs of a launch march through the phases in
+    // lock step: during the three memory phases ALL of them pull on HBM (saturated, ~10 B/clk per CU), during the compute phases
+    // none does (in-kernel clock stamps: the memory phases take the same time whether loads are 4 or 16 bytes wide).  The first
+    // workgroup of every CU (the first `stagger_n` of the grid) therefore starts (blockIdx % groups) * units * 1024 cycles
+    // late; the offsets persist through the later workgroups of the launch, and one group's memory phases meet the others'
+    // transforms.
+    if (stagger_units > 0 && (int)blockIdx.x < stagger_n) {
+        const int n = ((int)blockIdx.x % stagger_groups) * stagger_units;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     cx<float>* ldc = reinterpret_cast<cx<float>*>(lds_raw);
     float* ldf = reinterpret_cast<float*>(lds_raw);
@@ -496,21 +597,17 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     // (the twiddle table goes to LDS inside fused_gradient, under the operand loads of phase 1)
     if (alpha_vec != nullptr) scale *= alpha_vec[prob];
 
+    PNP_STAMP_DECL;
     PNP_STAMP(0);
     const RLane L(t);
     RImg R;
-    fused_gradient<OUTER>(R, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
+    fused_gradient<OUTER, NOPS>(R, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
                           yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
                           c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l,
-                          OUTER ? w_out + img : nullptr, OUTER ? mu_out + img : nullptr);
+                          OUTER ? w_out + img : nullptr, OUTER ? mu_out + img : nullptr PNP_STAMP_ARG);
     float* oi = out + img;
     if (MODE == FUSED_GRAD) {
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) st4(oi + L.goff(pass, h2, q), R[pass][h2][q]);
+        gst_passes<8>(oi, 0, L.voff, R);
         return;
     }
     PNP_STAMP(5);
@@ -560,39 +657,64 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
         haar_bayes_shrink<float, FN>(x[1], sigma * sigma);
     }
     PNP_STAMP(8);
+    // C -> R per column half, then error + store piece by piece.  The ground truth of the first half is requested once the
+    // registers of x[0] are free (written to the hand-over buffer), that of the second half right after the first has arrived:
+    // it is in flight during the whole first half.
     double err = 0.0;
+    auto finish = [&](auto WANT) {
+        constexpr bool ERR = decltype(WANT)::value;
+        f4 xa[8][2][1][1], xb[8][2][1][1];                      // ground truth of the two column halves: [pass][row01]
+        auto gt_load = [&](f4 (&dst)[8][2][1][1], int h2) {
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        // the ground truth of this half is requested before the hand-over, so that it arrives under it
-        f4 xr[8][2];
-        if (want_err) {
-#pragma unroll
-            for (int pass = 0; pass < 8; ++pass)
-#pragma unroll
-                for (int r01 = 0; r01 < 2; ++r01) xr[pass][r01] = ld4(xri + L.goff(pass, h2, r01));
-        }
-        __syncthreads();                                        // (h2 == 0: the noise estimate's barriers already passed; kept for symmetry)
-#pragma unroll
-        for (int i = 0; i < 64; ++i) ldf[cbase + 128 * i] = x[h2][i];
-        __syncthreads();
-        float e = 0.f;
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass)
-#pragma unroll
-            for (int r01 = 0; r01 < 2; ++r01) {
-                const f4 v = ld4(ldf + cbuf_r_addr(L, pass, r01));
-                if (want_err) {
-                    const f4 w4 = xr[pass][r01];
-                    const float d0 = w4.x - v.x, d1 = w4.y - v.y, d2 = w4.z - v.z, d3 = w4.w - v.w;
-                    e += d0 * d0;
-                    e += d1 * d1;
-                    e += d2 * d2;
-                    e += d3 * d3;
-                }
-                st4(oi + L.goff(pass, h2, r01), v);
+            for (int pass = 0; pass < 8; ++pass) {
+                if (h2 == 0) { gld<0>(dst[pass][0][0][0], xri + pass * 8192, L.voff); gld<1024>(dst[pass][1][0][0], xri + pass * 8192, L.voff); }
+                else { gld<512>(dst[pass][0][0][0], xri + pass * 8192, L.voff); gld<1536>(dst[pass][1][0][0], xri + pass * 8192, L.voff); }
             }
-        err += (double)e;
-    }
+        };
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            __syncthreads();                                    // (h2 == 1: the first half's readers are done)
+#pragma unroll
+            for (int i = 0; i < 64; ++i) ldf[cbase + 128 * i] = x[h2][i];
+            if (ERR && h2 == 0) gt_load(xa, 0);
+            __syncthreads();
+            if (ERR) {
+                if (h2 == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int pass = 0; pass < 8; ++pass) asm volatile("" : "+v"(xa[pass][0][0][0]), "+v"(xa[pass][1][0][0]));
+                    gt_load(xb, 1);
+                } else {
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // behind xb in the queue: the first half's 16 stores
+#pragma unroll
+                    for (int pass = 0; pass < 8; ++pass) asm volatile("" : "+v"(xb[pass][0][0][0]), "+v"(xb[pass][1][0][0]));
+                }
+            }
+            PNP_STAMP_NW(10 + 2 * h2);
+            float e = 0.f;
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                f4 v[2];
+#pragma unroll
+                for (int r01 = 0; r01 < 2; ++r01) {
+                    v[r01] = ld4(ldf + cbuf_r_addr(L, pass, r01));
+                    if (ERR) {
+                        const f4 df = (h2 == 0 ? xa[pass][r01][0][0] : xb[pass][r01][0][0]) - v[r01];
+                        e += df.x * df.x;
+                        e += df.y * df.y;
+                        e += df.z * df.z;
+                        e += df.w * df.w;
+                    }
+                }
+                if (h2 == 0) { gst<0>(oi + pass * 8192, L.voff, v[0]); gst<1024>(oi + pass * 8192, L.voff, v[1]); }
+                else { gst<512>(oi + pass * 8192, L.voff, v[0]); gst<1536>(oi + pass * 8192, L.voff, v[1]); }
+            }
+            err += (double)e;
+            PNP_STAMP_NW(11 + 2 * h2);
+        }
+    };
+    if (want_err) finish(std::true_type{});
+    else finish(std::false_type{});
     if (sse_out != nullptr && want_err) {
         err = wave_sum(err);
         __syncthreads();
@@ -608,6 +730,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     PNP_STAMP(9);
+    PNP_STAMP_FLUSH;
 }
 
 // plan internals live in csmri.hip (pnp_csmri_svrg_step / pnp_csmri_grad_sel); the kernel only needs the plan's twiddle table.
@@ -618,16 +741,36 @@ int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* 
                        void* stream, void* w_out, void* mu_out) {
     const float scale = (float)(alpha / ((double)FN * (double)FN));
     hipStream_t s = (hipStream_t)stream;
+    // stagger (see the kernel): only launches of more than one workgroup per CU pay for it and profit from it
+    static int num_cu = 0, st_groups = 2, st_units = 40;    // same-box sweep (tools/dev/stagger_sweep.py): 0.588 ms per config-2 step without, 0.575 with (2, 40), slower from (8, 20) on
+    if (num_cu == 0) {
+        int d0 = 0;
+        hipDeviceProp_t prop;
+        PNP_CHECK_HIP(hipGetDevice(&d0));
+        PNP_CHECK_HIP(hipGetDeviceProperties(&prop, d0));
+        num_cu = prop.multiProcessorCount;
+        if (const char* ev = getenv("PNP_FUSED_STAGGER")) {   // "groups,units" (A/B timing); "0" switches it off
+            int g = 0, u = 0;
+            if (sscanf(ev, "%d,%d", &g, &u) == 2 && g >= 1 && u >= 0) { st_groups = g; st_units = u; }
+            else st_units = 0;
+        }
+    }
+    const int stagger_units = batch > num_cu ? st_units : 0;
     // > 64 KiB of dynamic LDS needs the opt-in, once per device (the attribute is per device)
     static unsigned long long attr_done = 0;
     int dev = 0;
     PNP_CHECK_HIP(hipGetDevice(&dev));
+    // epilogue operands as the kernel takes them: (c1, beta) first, then (c2, gamma); a lone c2 moves to the first slot
+    int nops = (c1 != nullptr ? 1 : 0) + (c2 != nullptr ? 1 : 0);
+    if (c1 == nullptr && c2 != nullptr) { c1 = c2; beta = gamma; c2 = nullptr; }
+    const bool outer = w_out != nullptr;
     if (!((attr_done >> (dev & 63)) & 1ull)) {
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
-        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+#define PNP_FUSED_ATTR(...) PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES))
+        PNP_FUSED_ATTR(0, false, 0); PNP_FUSED_ATTR(0, false, 1); PNP_FUSED_ATTR(0, false, 2);
+        PNP_FUSED_ATTR(1, false, 0); PNP_FUSED_ATTR(1, false, 1); PNP_FUSED_ATTR(1, false, 2);
+        PNP_FUSED_ATTR(2, false, 0); PNP_FUSED_ATTR(2, false, 1); PNP_FUSED_ATTR(2, false, 2);
+        PNP_FUSED_ATTR(0, true, 0); PNP_FUSED_ATTR(1, true, 0);
+#undef PNP_FUSED_ATTR
         attr_done |= 1ull << (dev & 63);
     }
 #define PNP_FUSED_LAUNCH(...)                                                                                             \
@@ -635,13 +778,17 @@ int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* 
                                                        (const cx<float>*)twtab, scale, (const float*)alpha_vec, (float)beta,    \
                                                        (const float*)c1, (float)gamma, (const float*)c2, (float*)out,         \
                                                        (float)sigma_modifier, (float)fallback_sigma, (const float*)xrec,      \
-                                                       sse_out, (float*)sigma_out, (float*)w_out, (float*)mu_out)
-    if (w_out != nullptr) {                                     // the outer refresh folded into the first inner iteration
-        if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0, true);
-        else PNP_FUSED_LAUNCH(1, true);
-    } else if (mode == FUSED_GRAD) PNP_FUSED_LAUNCH(2);
-    else if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0);
-    else PNP_FUSED_LAUNCH(1);
+                                                       sse_out, (float*)sigma_out, (float*)w_out, (float*)mu_out, num_cu,      \
+                                                       st_groups, stagger_units)
+#define PNP_FUSED_BY_NOPS(MD)                                                     \
+    do { if (nops == 0) PNP_FUSED_LAUNCH(MD, false, 0); else if (nops == 1) PNP_FUSED_LAUNCH(MD, false, 1); else PNP_FUSED_LAUNCH(MD, false, 2); } while (0)
+    if (outer) {                                                // the outer refresh folded into the first inner iteration
+        if (mode == FUSED_FULL) PNP_FUSED_LAUNCH(0, true, 0);
+        else PNP_FUSED_LAUNCH(1, true, 0);
+    } else if (mode == FUSED_GRAD) PNP_FUSED_BY_NOPS(2);
+    else if (mode == FUSED_FULL) PNP_FUSED_BY_NOPS(0);
+    else PNP_FUSED_BY_NOPS(1);
+#undef PNP_FUSED_BY_NOPS
 #undef PNP_FUSED_LAUNCH
     PNP_CHECK_LAUNCH();
     return PNP_OK;

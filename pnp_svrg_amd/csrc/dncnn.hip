@@ -789,6 +789,36 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
 }
 }  // namespace
 
+// ---- test hooks: one middle layer on caller-provided buffers (guard-band tests)
+extern "C" size_t pnp_dncnn_debug_w44_floats(void) { return wino44_weight_floats(1); }
+
+extern "C" int pnp_dncnn_debug_w44_weights(pnp_dncnn_plan* p, int layer, float* dst, void* stream) {
+    PNP_CHECK_ARG(p && dst && layer >= 0 && layer < p->n_mid, "bad argument");
+    PNP_CHECK_HIP(hipMemcpyAsync(dst, p->upack44 + (size_t)layer * wino44_weight_floats(1), wino44_weight_floats(1) * sizeof(float),
+                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PNP_OK;
+}
+
+extern "C" int pnp_dncnn_debug_mid_layer(pnp_dncnn_plan* p, int layer, const float* in, float* out, const float* w44_override,
+                                         int w44_rows, void* stream) {
+    PNP_CHECK_ARG(p && in && out && layer >= 0 && layer < p->n_mid && w44_rows >= 0 && w44_rows <= 2, "bad argument");
+    PNP_CHECK_ARG(w44_override == nullptr || p->use_wino == 5, "w44_override needs the F(4x4,3x3) kernel (mode 5)");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = p->H, W = p->W, B = p->batch, l = layer;
+    const int ntiles = B * (H / TR) * (W / TC);
+    const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
+    if (p->use_wino == 5)
+        return wino44_layer(in, out, w44_override ? w44_override : p->upack44 + (size_t)l * wino44_weight_floats(1),
+                            p->bias + (size_t)l * C, p->zeros, H, W, B, p->num_cu, p->slope, s, w44_rows);
+    PNP_CHECK_ARG(p->slope == 0.f, "the hook runs the ReLU builds of the direct / F(2,3) kernels");
+    if (p->use_wino)
+        k_mid_wino<true><<<grid, 256, 0, s>>>(in, out, p->upack + (size_t)l * 4 * WINO_U * 64, p->bias + (size_t)l * C, p->zeros, H, W, ntiles);
+    else
+        k_mid<true><<<grid, 256, 0, s>>>(in, out, p->wpack + (size_t)l * 4 * 2 * KSTEPS_HALF * 64, p->bias + (size_t)l * C, p->zeros, H, W, ntiles);
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
+}
+
 extern "C" int pnp_dncnn_set_affine(pnp_dncnn_plan* p, const float* b_first, float b_last, float negative_slope) {
     PNP_CHECK_ARG(p != nullptr, "null plan");
     PNP_CHECK_ARG(negative_slope >= 0.f && negative_slope < 1.f, "negative_slope must be in [0, 1)");

@@ -557,12 +557,11 @@ void wino44_pack_weights(const float* w_mid, int n_mid, float* out) {
 }
 
 int wino44_layer(const float* in, float* out, const float* upack_layer, const float* bias, const float* zeros, int H, int W,
-                 int batch, int num_cu, float slope, hipStream_t s) {
+                 int batch, int num_cu, float slope, hipStream_t s, int force) {
     // 8 x 64 regions (72 accumulator quads per wave) in full waves of one region per CU; what is left -- a launch smaller than
     // the chip, or the last, partly filled wave -- goes through the 4 x 64 form, twice as many regions of half the work (one
     // 256 x 256 image: 256 regions instead of 128; three images: 256 + 256 instead of 384 in two waves).  Same bits either way.
-    // PNP_W44_ROWS = 1 / 2 forces a form for the whole layer.
-    static const int force = getenv("PNP_W44_ROWS") ? atoi(getenv("PNP_W44_ROWS")) : 0;
+    // force = 1 / 2 (test hook pnp_dncnn_debug_mid_layer only) takes one form for the whole layer.
     const int units = batch * (H / 8) * (W / w44::TC);
     int full = force == 1 ? 0 : force == 2 ? units : (units / num_cu) * num_cu;              // units done as 8 x 64 regions
     if (force == 0 && 2 * (units - full) > num_cu) full = units;      // (more than half a wave left: one more 8 x 64 wave is cheaper than two 4 x 64 waves)

@@ -216,6 +216,19 @@ class DncnnPlan:
         N.call('pnp_dncnn_profile_end', self._h, ctypes.byref(ms), ctypes.byref(n))
         return ms.value, n.value
 
+    def debug_w44_weights(self, layer):
+        """packed F(4x4,3x3) weights of one middle layer as a device tensor (test hook)"""
+        n = N.lib().pnp_dncnn_debug_w44_floats()
+        dst = torch.empty(n, dtype=torch.float32, device='cuda')
+        N.call('pnp_dncnn_debug_w44_weights', self._h, int(layer), _p(dst), _stream())
+        return dst
+
+    def debug_mid_layer(self, layer, x, out, w44=None, rows=0):
+        """one 64->64 layer on caller-provided activations [B,64,H,W] (test hook: guard bands around the buffers)"""
+        assert x.dtype == torch.float32 and tuple(x.shape) == (self.B, 64, self.H, self.W) and tuple(out.shape) == tuple(x.shape)
+        N.call('pnp_dncnn_debug_mid_layer', self._h, int(layer), _p(x), _p(out), _p(w44), int(rows), _stream())
+        return out
+
     def forward(self, x, out=None):
         """raw network residual; x: float32 [B,H,W]."""
         assert x.dtype == torch.float32 and tuple(x.shape) == (self.B, self.H, self.W)

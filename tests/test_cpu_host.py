@@ -299,6 +299,20 @@ def test_w44_accumulators_untouched():
     assert '0 problem(s)' in out.stdout
 
 
+def test_fused_loads_untouched():
+    """The global loads of the one-kernel iteration (csrc/csmri_fused.hip) are hand-issued inline asm with hand-counted
+    `s_waitcnt vmcnt(N)` in front of their uses: hipcc does not know that their results arrive later and could read, overwrite
+    or SPILL a destination register behind the load (it did, under register pressure, in a first version).
+    tools/check_fused_isa.py compiles the file to assembly and verifies for every instantiation, over all paths, that no
+    instruction names a destination register of such a load before a wait that covers it."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_fused_isa.py')], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert out.stdout.count(' 0 violations') == 11 and 'VIOLATION' not in out.stdout
+
+
 def test_legacy_choice_matches_numpy():
     """`legacy_rng.choice` (C restatement of np.random.choice(..., replace=False), csrc/legacy_rng.cpp) against NumPy itself:
     the same values and dtype, and the same stream afterwards (uniform and cached-Gaussian draws that follow), for the draws the

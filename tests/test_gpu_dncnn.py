@@ -152,7 +152,7 @@ def test_simplecnn_family(name):
     w = {'n_layers': np.int64(4)}
     for i in range(4):
         w[f'conv{i}.weight'] = g[f'{name}_conv{i}.weight']
-    for wino in (5, 4, 1, 0):
+    for wino in (5, 1, 0):
         r = ops.DncnnPlan(w, 64, 64, 1, winograd=wino).forward(dev(g['net64_in'][None])).cpu().numpy()[0]
         assert np.abs(r - g[f'{name}_out']).max() <= 2e-5
 
@@ -239,3 +239,45 @@ def test_conv_kernels_against_float64(scale):
     # the two-dimensional transform pays for its 4x fewer multiply-adds with ~4-5x the rounding error of the direct form on
     # white-noise weights (transform entries up to 8 and 1/24); on the reference's weights: 8e-7 vs 4e-7 (test_winograd_vs_direct)
     assert err[0] < 2e-6 and err[1] < 2e-6 and err[5] < 1e-5
+
+
+def test_wino44_guard_bands():
+    """The F(4x4,3x3) layer (`k_mid_wino44`: LDS-DMA halo loads that lean on the buffer descriptor's range check, a weight
+    stream prefetched a ring ahead, a prefetch of the NEXT region's first chunks) on CALLER-provided buffers with canary-filled
+    guard bands in front of and behind the input, the output and the weights: both region forms (8 x 64: `Geo<2>`, 4 x 64:
+    `Geo<1>`), the second-launch tail path (a last, at most half-full wave goes through the 4 x 64 form), a 72 x 128 and a
+    256 x 256 B = 5 case.  Asserts (a) every canary intact -- nothing is written outside `out`; (b) the result equals the direct
+    kernel's on the same input to fp32 rounding -- a read that strayed into a band (NaN canaries) would poison it."""
+    from pnp_svrg_amd import ops
+    from pnp_svrg_amd.denoisers import random_dncnn_weights
+    w = random_dncnn_weights(4, seed=9)
+    rng = np.random.default_rng(21)
+    GUARD = 1 << 18                                              # floats (1 MiB) on each side
+    # rows: 0 = the production choice (256 x 256 B = 5: 640 regions of 8 x 64 = two full waves of 256 + a 128-region rest -> the
+    # second launch in the 4 x 64 form), 1 / 2 = one form for the whole layer
+    cases = [(72, 128, 3, 0), (256, 256, 5, 0), (256, 256, 5, 1), (256, 256, 5, 2), (8, 64, 1, 0), (64, 192, 2, 0), (72, 128, 3, 2)]
+    for (H, Wd, B, rows) in cases:
+        n = B * 64 * H * Wd
+        plan5 = ops.DncnnPlan(w, H, Wd, B, winograd=5)
+        plan0 = ops.DncnnPlan(w, H, Wd, B, winograd=0)
+        x = rng.standard_normal(n).astype(np.float32)
+
+        def banded(nfloats, fill):
+            t = torch.full((nfloats + 2 * GUARD,), float('nan'), dtype=torch.float32, device='cuda')
+            t[GUARD:GUARD + nfloats] = fill
+            return t
+        xin = banded(n, torch.from_numpy(x).cuda())
+        yout = banded(n, 0.0)
+        wk = plan5.debug_w44_weights(1)
+        wb = banded(wk.numel(), wk)
+        vin, vout, vw = xin[GUARD:GUARD + n].view(B, 64, H, Wd), yout[GUARD:GUARD + n].view(B, 64, H, Wd), wb[GUARD:GUARD + wk.numel()]
+        assert vin.data_ptr() % 16 == 0 and vout.data_ptr() % 16 == 0 and vw.data_ptr() % 16 == 0
+        plan5.debug_mid_layer(1, vin, vout, w44=vw, rows=rows)
+        ref = torch.empty((B, 64, H, Wd), dtype=torch.float32, device='cuda')
+        plan0.debug_mid_layer(1, torch.from_numpy(x).cuda().view(B, 64, H, Wd), ref)
+        torch.cuda.synchronize()
+        for t, nn in ((xin, n), (yout, n), (wb, wk.numel())):
+            assert torch.isnan(t[:GUARD]).all() and torch.isnan(t[GUARD + nn:]).all(), (H, Wd, B, rows)
+        assert torch.equal(xin[GUARD:GUARD + n], torch.from_numpy(x).cuda()) and torch.equal(vw, wk)
+        assert torch.isfinite(vout).all()
+        assert (vout - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (H, Wd, B, rows)

@@ -459,6 +459,18 @@ def test_one_kernel_iteration_equals_four_kernels():
     gf2 = p.grad(z, bits=batch.bits, yh=batch.yh_full, alpha=0.7, alpha_vec=batch.inv_m0, beta=0.5, c1=w)
     # (different kernels; since the complex products spell their fused multiply-adds out, common.h, they may even agree bit for bit)
     assert (gf1 - gf2).abs().max().item() <= 2e-6 * max(1.0, gf2.abs().max().item())
+    # every combination of epilogue operands (the kernel is instantiated per operand count; a lone c2 takes the first slot),
+    # gradient-only form against the streaming kernels, whole iteration against gradient + prox
+    for kw2 in (dict(), dict(beta=0.5, c1=w), dict(gamma=-0.25, c2=mu), dict(beta=1.0, c1=z, gamma=-lr, c2=mu)):
+        for bb in (None, w):
+            ga = pf.grad(z, bits=selbits[0], b=bb, alpha=-lr / mb, **kw2)
+            gb = p.grad(z, bits=selbits[0], b=bb, alpha=-lr / mb, **kw2)
+            assert (ga - gb).abs().max().item() <= 2e-6 * max(1.0, gb.abs().max().item()), (kw2.keys(), bb is None)
+        want2, want2_sse, _ = ops.prox_tv(p.grad(z, bits=selbits[0], b=w, alpha=-lr / mb, **kw2), xrec=batch.xrec)
+        got2, sse2, _ = p.svrg_step(z, w, selbits[0], alpha=-lr / mb, xrec=batch.xrec,
+                                    sse=torch.empty(B, dtype=torch.float64, device='cuda'), **kw2)
+        assert (got2 - want2).abs().max().item() <= 2e-5, kw2.keys()
+        np.testing.assert_allclose(sse2.cpu().numpy(), want2_sse.cpu().numpy(), rtol=1e-4)
 
 
 @pytest.mark.parametrize('prox_kind', ['tv', 'dncnn'])

@@ -29,7 +29,8 @@ buf = (ctypes.c_ulonglong * (nb * 16))()
 lib.pnp_debug_fused_stamps.restype = ctypes.c_int
 lib.pnp_debug_fused_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.pnp_debug_fused_stamps(buf, nb) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 16)[:, :10].astype(np.int64)
+st_all = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 16)
+st = st_all[:, :10].astype(np.int64)
 d = np.diff(st, axis=1).astype(np.float64)
 names = ['1 operand loads a, b (+ twiddles, selector bits)', '1 rows forward FFT', '2 columns (two halves)', '3 rows inverse FFT',
          '3 epilogue operands c1, c2', '4 re-layout', '5 noise estimate (median)', '5 Haar BayesShrink', '5 error + store']
@@ -40,5 +41,19 @@ print(f'B = {B}: shader cycles per workgroup, median over all / over the later h
 for i, n in enumerate(names):
     print(f'  {n:55s} {np.median(d[:, i]):9.0f} {np.median(d[late, i]):9.0f}   {100 * np.median(d[late, i]) / np.median(tot[late]):5.1f} %')
 print(f'  {"whole workgroup":55s} {np.median(tot):9.0f} {np.median(tot[late]):9.0f}')
-span = st[:, 9].max() - st[:, 0].min()
-print(f'  launch span {span} cycles; sum of workgroup times / (256 CUs x span) = {tot.sum() / (256 * span):.3f}')
+if st_all[:, 10].any():
+    fine = st_all[:, [8, 10, 11, 12, 13, 9]].astype(np.int64)
+    df = np.diff(fine, axis=1).astype(np.float64)
+    for nm, i in (("5a x[0] -> buffer, ground truth of half 0 requested and waited for", 0), ("5b half 0: pieces read, error, stores issued", 1),
+                  ("5c x[1] -> buffer, wait for the ground truth of half 1", 2), ("5d half 1: pieces read, error, stores issued", 3),
+                  ("5e error reduction, stores drained", 4)):
+        print(f'     {nm:72s} {np.median(df[late, i]):9.0f}')
+# memory phases as effective bandwidth per CU (bytes / cycle): P1 reads a, b (512 KB); the epilogue c1, c2 (512 KB); the last
+# phase reads the ground truth and writes the result (512 KB)
+for nm, i in (('operand loads', 0), ('epilogue operands', 4), ('error + store', 8)):
+    print(f'  {nm:20s}: {524288 / np.median(d[late, i]):6.1f} B/clk per CU')
+# start times of the workgroups relative to the first (per round of 256): does a start-up stagger persist?
+s0 = np.sort(st[:, 0] - st[:, 0].min())
+for r in range(0, nb, 256):
+    blk = s0[r:r + 256]
+    print(f'  workgroups {r:4d}..{r + len(blk) - 1:4d} by start time: first {blk[0]:9d}  median {int(np.median(blk)):9d}  last {blk[-1]:9d}  (spread {blk[-1] - blk[0]})')

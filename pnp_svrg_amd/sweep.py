@@ -268,7 +268,7 @@ def make_runner(images, problem='csmri', algorithm='svrg', denoiser='tv', *, eta
             # engine can be captured at all (an NLM prox ping-pongs between buffers and cannot: eager steps)
             if (graph and idx_d is None and hasattr(eng, 'run_outer') and n % T2 == 0 and eng.s % T2 == 0
                     and (n > T2 or eng.graph is not None) and eng.graph_ok()):
-                eng.run_outer(n // T2)
+                eng.run_outer(n // T2)                          # (captures first when that has not happened yet: `warm`)
             else:
                 for s in range(self.done, self.done + n):
                     if idx_d is None:
@@ -305,6 +305,14 @@ def make_runner(images, problem='csmri', algorithm='svrg', denoiser='tv', *, eta
         for c in state:
             c.advance(n)
 
+    def warm(state):
+        """Capture the hipGraphs of the batches that will replay them (a timed run then starts with replays, not with the
+        capture's own warm-up pass); state and results are unchanged."""
+        for c in state:
+            eng = c.eng
+            if (graph and c.idx_d is None and hasattr(eng, 'run_outer') and eng.s % T2 == 0 and eng.graph is None and eng.graph_ok()):
+                eng.capture()
+
     def collect(state):
         return sorted((r for c in state for r in c.results()), key=lambda r: r['id'])
 
@@ -313,7 +321,7 @@ def make_runner(images, problem='csmri', algorithm='svrg', denoiser='tv', *, eta
         advance(state, n_inner)
         return collect(state)
 
-    run.prepare, run.advance, run.collect = prepare, advance, collect
+    run.prepare, run.advance, run.collect, run.warm = prepare, advance, collect, warm
     run.names = (_REF_NAMES[problem], 'CNN' if callable(denoiser) else _REF_NAMES.get(denoiser, str(denoiser)), 'pnp_' + algorithm)
     return run
 

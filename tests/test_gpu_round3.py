@@ -145,7 +145,7 @@ def test_sweep_runner_deblur_nlm_saga_vs_oracle(dtype):
     (constructor draws, then per iteration select_mb + np.random.choice(hist_size, 1): every item its own stream)."""
     from pnp_svrg_amd import sweep
     from oracle import denoise as od, problems as op
-    n, mb, hist, n_it, eta = 64, 300, 4, 5, 2e8
+    n, mb, hist, n_it, eta = 64, 300, 4, 5, 1e7           # (the reference's blur has gain 1 / sqrt(N): the step is stable below ~ 2 N^2 = 3e7)
     imgs = _smooth_images(n, 2, 3)
     items = [{'id': 0, 'image': 0, 'alpha': 1.0, 'snr': 20.0, 'seed': 0}, {'id': 1, 'image': 1, 'alpha': 1.0, 'snr': 20.0, 'seed': 5},
              {'id': 2, 'image': 0, 'alpha': 1.0, 'snr': 10.0, 'seed': 2}]
@@ -163,7 +163,7 @@ def test_sweep_runner_deblur_nlm_saga_vs_oracle(dtype):
         ref = np.array(ro['psnr_per_iter'])
         assert len(ref) == n_it + 1 and r['psnr_init'] == ref[0]
         if dtype == torch.float64:
-            assert list(r['psnr_trace']) == list(ref[1:])
+            assert np.array_equal(r['psnr_trace'], ref[1:]) and np.isfinite(ref).all()
             assert np.abs(r['z'].ravel() - ro['z']).max() <= 1e-9
         else:
             assert np.abs(r['psnr_trace'] - ref[1:]).max() <= PSNR_TOL
@@ -210,7 +210,7 @@ def test_sweep_runner_cells_and_hist_size_grid(tmp_path):
     n = 64
     imgs = _smooth_images(n, 2, 11)
     items = sweep.make_items(2, [1.0], [20.0])
-    for problem, eta, mb in (('csmri', 5e2, 100), ('deblur', 2e8, 300)):
+    for problem, eta, mb in (('csmri', 5e2, 100), ('deblur', 1e7, 300)):
         for algo in sweep.ALGORITHMS:
             its = items if problem == 'deblur' else sweep.make_items(2, [0.3, 0.5], [20.0])
             run = sweep.make_runner(imgs, problem, algo, 'tv', eta=eta, n_inner=8, mini_batch_size=mb, T2=4, hist_size=3, H=n, W=n)
@@ -227,7 +227,7 @@ def test_sweep_runner_cells_and_hist_size_grid(tmp_path):
 
     def mk(eta, hist_size):
         return sweep.make_runner(imgs, 'deblur', 'saga', 'tv', eta=eta, n_inner=6, mini_batch_size=300, hist_size=hist_size, H=n, W=n)
-    rows = sweep.grid_search(items, mk, {'eta': [1e8, 3e8], 'hist_size': [2, 5]})
+    rows = sweep.grid_search(items, mk, {'eta': [5e6, 1e7], 'hist_size': [2, 5]})
     assert [r['id'] for r in rows] == [0, 1] and all(set(r['params']) == {'eta', 'hist_size'} for r in rows)
     sweep.write_tuning_csv(str(tmp_path / 't.csv'), rows, problem='DeblurSR', denoiser='TV', algorithm='pnp_saga')
     txt = (tmp_path / 't.csv').read_text().splitlines()

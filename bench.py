@@ -157,13 +157,16 @@ def _cpu_baseline_here(workload, weights, budget_s=12.0):
 
 
 def _traffic(key):
+    """(HBM bytes per launch / step from the builder's PMC profile, where that number comes from) -- a constant read from
+    profiles/traffic.json, NOT something the run that prints the line measured."""
     tj = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tj):
         try:
-            return json.load(open(tj)).get(key)
+            t = json.load(open(tj))
+            return t.get(key), t.get(key + '_source')
         except Exception:
-            return None
-    return None
+            return None, None
+    return None, None
 
 
 class Workload:
@@ -215,7 +218,8 @@ class Workload:
                                '0': 'pnp::k_mid (64->64 3x3 conv, direct implicit GEMM on v_mfma_f32_16x16x4_f32)'}.get(mode, mode),
                     # achieved / frac: what the matrix cores EXECUTE per second against their peak
                     'achieved': round(ex, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ex / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': _traffic(f'k_mid_B{B}'),
+                    'frac': round(ex / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': _traffic(f'k_mid_B{B}')[0],
+                    'traffic_source': _traffic(f'k_mid_B{B}')[1],
                     'launch_ms': round(ms, 4), 'launches_timed': launches,
                     'flops_per_launch': int(flops / red), 'algorithmic_flops_per_launch': flops,
                     'algorithmic_tflops': round(alg, 2), 'winograd_reduction': red}
@@ -224,10 +228,11 @@ class Workload:
             alg = TV_BYTES_PER_ITER * B
             ach = alg / dt_step / 1e9
             return {'bound': 'hbm',
-                    'kernel': 'whole inner iteration = pnp::k_svrg_iter<true> (SVRG step through the masked FFT, noise estimate, Haar prox, '
-                              'error sum in one kernel, image register-resident) + 1/T2 of k_draw_thr and of the full-gradient refresh',
+                    'kernel': 'whole inner iteration = pnp::k_svrg_iter (SVRG step through the masked FFT, noise estimate, Haar prox, error sum in '
+                              'one kernel, image register-resident, every global access 16 bytes per lane; the outer full-gradient refresh folded '
+                              'into the first inner iteration) + 1/T2 of k_draw_thr',
                     'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                    'traffic': _traffic(f'tv_step_B{B}'), 'bytes_per_step': alg}
+                    'traffic': _traffic(f'tv_step_B{B}')[0], 'traffic_source': _traffic(f'tv_step_B{B}')[1], 'bytes_per_step': alg}
         # saga-nlm: the NLM prox dominates (VALU-bound patch search); the table update is the HBM-bound part
         ms = self.nlm_ms
         fl = NLM_FLOP_PER_PIXEL * H * W * B
@@ -236,6 +241,10 @@ class Workload:
                 'kernel': 'pnp::k_nlm_strip<float,5,5> (11x11 search window x 5x5 patches, neighbour patches in a register strip fed from an LDS-staged tile, f32; nominal FLOPs before '
                           'the reference\'s early exits and border clipping)',
                 'achieved': round(ach, 2), 'peak': F32_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / F32_VALU_PEAK_TFLOPS, 4),
+                'frac_kind': 'NOMINAL: 5 FLOPs per patch element before the reference\'s early exits, over the f32 vector peak -- not a hardware fraction',
+                'valu_issue_frac': 0.53,
+                'valu_issue_frac_source': 'profiles/r02e_nlm_sq_counters.txt (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of k_nlm_strip, builder PMC run): '
+                                          'the share of wave time in which the vector ALU issues -- the hardware-side figure next to the nominal frac',
                 'traffic': None, 'launch_ms': round(ms, 4), 'flops_per_launch': fl,
                 'saga_table_update': {'bound': 'hbm', 'bytes_per_step': SAGA_BYTES_PER_ITER * B,
                                       'launch_ms': round(self.saga_ms, 4),

@@ -13,6 +13,8 @@
 // 16-lane-stride wave shuffles between the four lanes of a column.  The image is read once and
 // written once.
 #include "common.h"
+#include <mutex>
+#include <vector>
 #include "reduce.h"
 #include "prox_tv.h"
 #include <cstdlib>
@@ -112,20 +114,33 @@ __global__ __launch_bounds__(64) void k_shrink_cols(const T* zin, T* zout, int W
 constexpr int kSmallBatch = 32;                                // up to this many images take the split form
 struct SmallProxScratch { void* sig_cols; double* partial; unsigned* counter; };
 
-// per-device scratch of the split form, allocated on first use (never inside a hipGraph capture: captured callers run
-// one eager warm-up call first, as every graph in this code base does)
-static int small_prox_scratch(SmallProxScratch** out) {
-    static SmallProxScratch tab[64] = {};
+// scratch of the split form, one set per (device, stream) -- two streams running a small-batch prox at the same time would
+// otherwise race on sig_cols and on the last-workgroup counter, and a captured graph bakes these pointers in, so
+// they are never freed or moved.  Allocated on first use (never inside a hipGraph capture: captured callers run one eager
+// warm-up call first, as every graph in this code base does); an entry is committed only once all of it exists.
+static int small_prox_scratch(SmallProxScratch** out, hipStream_t stream) {
+    struct Entry { int dev; hipStream_t stream; SmallProxScratch s; };
+    static std::vector<Entry*> tab;
+    static std::mutex mu;
     int dev = 0;
     PNP_CHECK_HIP(hipGetDevice(&dev));
-    SmallProxScratch& s = tab[dev & 63];
-    if (s.sig_cols == nullptr) {
-        PNP_CHECK_HIP(hipMalloc(&s.sig_cols, (size_t)kSmallBatch * 256 * sizeof(double)));
-        PNP_CHECK_HIP(hipMalloc((void**)&s.partial, (size_t)kSmallBatch * 16 * sizeof(double)));
-        PNP_CHECK_HIP(hipMalloc((void**)&s.counter, (size_t)kSmallBatch * sizeof(unsigned)));
-        PNP_CHECK_HIP(hipMemset(s.counter, 0, (size_t)kSmallBatch * sizeof(unsigned)));
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry* e : tab)
+        if (e->dev == dev && e->stream == stream) { *out = &e->s; return PNP_OK; }
+    SmallProxScratch n = {};
+    hipError_t err = hipMalloc(&n.sig_cols, (size_t)kSmallBatch * 256 * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc((void**)&n.partial, (size_t)kSmallBatch * 16 * sizeof(double));
+    if (err == hipSuccess) err = hipMalloc((void**)&n.counter, (size_t)kSmallBatch * sizeof(unsigned));
+    if (err == hipSuccess) err = hipMemset(n.counter, 0, (size_t)kSmallBatch * sizeof(unsigned));
+    if (err != hipSuccess) {
+        if (n.sig_cols) (void)hipFree(n.sig_cols);
+        if (n.partial) (void)hipFree(n.partial);
+        if (n.counter) (void)hipFree(n.counter);
+        set_error(std::string("small_prox_scratch: ") + hipGetErrorString(err));
+        return PNP_ERR_HIP;
     }
-    *out = &s;
+    tab.push_back(new Entry{dev, stream, n});
+    *out = &tab.back()->s;
     return PNP_OK;
 }
 
@@ -160,7 +175,7 @@ int launch_prox(const void* zin, void* zout, int W, int batch, const void* sigma
                 const void* xrec, double* sse, void* sigma_out, hipStream_t s) {
     if (batch <= kSmallBatch && getenv("PNP_PROX_NO_SPLIT") == nullptr) {
         SmallProxScratch* sc = nullptr;
-        const int rc = small_prox_scratch(&sc);
+        const int rc = small_prox_scratch(&sc, s);
         if (rc != PNP_OK) return rc;
         const dim3 grid(W / 16, batch);
         if (sigma_in == nullptr) {

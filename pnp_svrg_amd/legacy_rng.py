@@ -19,10 +19,14 @@ _inplace = None
 def _state_in_place():
     """(address, ok): the global RandomState's MT19937 state struct, checked once against get_state()."""
     global _inplace
-    bg = np.random.mtrand._rand._bit_generator
-    if type(bg).__name__ != 'MT19937':                          # np.random.set_bit_generator(...): not the legacy stream's layout
+    try:                                                        # (private NumPy attributes: any surprise -> the get_state path)
+        bg = np.random.mtrand._rand._bit_generator
+        if type(bg).__name__ != 'MT19937':                      # np.random.set_bit_generator(...): not the legacy stream's layout
+            return 0, False
+        addr = bg.ctypes.state_address
+    except AttributeError:
+        _inplace = False
         return 0, False
-    addr = bg.ctypes.state_address
     if _inplace is None:
         st = np.random.get_state()
         key = np.frombuffer((ctypes.c_uint32 * 624).from_address(addr), dtype=np.uint32)
@@ -32,26 +36,37 @@ def _state_in_place():
 
 
 def choice(pool, size):
-    """np.random.choice(pool, size, replace=False) for a 1-D integer array `pool` or an int (= arange(pool)); int64 result."""
-    if isinstance(pool, (int, np.integer)):
+    """np.random.choice(pool, size, replace=False) for a 1-D integer array `pool` or an int (= arange(pool)); int64 result.
+    Anything else -- float / object pools (NumPy returns the pool's dtype), 0-d or n-d arrays, sizes that are not plain
+    non-negative ints -- goes to np.random.choice itself, with NumPy's own results and errors."""
+    if isinstance(pool, (int, np.integer)) and not isinstance(pool, (bool, np.bool_)):
         pop, pool_arr, pool_ptr = int(pool), None, None
     else:
-        pool_arr = np.ascontiguousarray(pool, dtype=np.int64)
+        pa = np.asarray(pool)
+        if pa.ndim != 1 or pa.dtype.kind not in 'iu':
+            return np.random.choice(pool, size, replace=False)
+        pool_arr = np.ascontiguousarray(pa, dtype=np.int64)
         pop, pool_ptr = pool_arr.shape[0], pool_arr.ctypes.data
+    if not isinstance(size, (int, np.integer)) or isinstance(size, (bool, np.bool_)):
+        return np.random.choice(pool, size, replace=False)
     size = int(size)
-    if pool_arr is not None and pool_arr.ndim != 1 or size < 0 or size > pop or pop < 1:
+    if size < 0 or size > pop or pop < 1:
         return np.random.choice(pool, size, replace=False)          # NumPy's own errors / corner cases
     work = _work.get(pop)
     if work is None:
         work = _work[pop] = np.empty(pop, np.int32)
     out = np.empty(size, np.int64)
-    rs = np.random.mtrand._rand
-    with rs._bit_generator.lock:
-        addr, ok = _state_in_place()
-        if ok:
-            N.call('pnp_legacy_choice', addr, ctypes.cast(addr + 624 * 4, ctypes.POINTER(ctypes.c_int)), pool_ptr, pop, size,
-                   work.ctypes.data, out.ctypes.data)
-            return out
+    try:
+        lock = np.random.mtrand._rand._bit_generator.lock
+    except AttributeError:
+        lock = None
+    if lock is not None:
+        with lock:
+            addr, ok = _state_in_place()
+            if ok:
+                N.call('pnp_legacy_choice', addr, ctypes.cast(addr + 624 * 4, ctypes.POINTER(ctypes.c_int)), pool_ptr, pop, size,
+                       work.ctypes.data, out.ctypes.data)
+                return out
     st = np.random.get_state()
     if st[0] != 'MT19937':
         return np.random.choice(pool, size, replace=False)          # another bit generator: NumPy's own draw

@@ -222,7 +222,8 @@ class CSMRI(Problem):
         return mb
 
     def _locs(self):
-        """np.flatnonzero(self.mask) (CSMRI.py:71), computed once: the mask does not change after construction."""
+        """np.flatnonzero(self.mask) (CSMRI.py:71), computed once.  ASSUMPTION: the mask is frozen after construction -- the
+        reference recomputes it on every select_mb; code that edits `problem.mask` afterwards must delete `problem._mask_locs`."""
         locs = self.__dict__.get('_mask_locs')
         if locs is None:
             locs = self._mask_locs = np.asarray(np.flatnonzero(self.mask))

@@ -356,3 +356,22 @@ def test_problem_default_device_is_current_device(monkeypatch):
     with pytest.raises(Exception, match='not the current device'):
         P.Problem(None, 8, 8, img=img, device='cuda:0')
     assert P.Problem(None, 8, 8, img=img, upload=False).device.type == 'cuda'      # host-only construction: no device touched
+
+
+def test_legacy_choice_delegates_outside_its_contract():
+    """pools that are not 1-D integer arrays (float / 0-d / 2-D) and odd sizes go to np.random.choice itself:
+    NumPy's dtype, values, errors and stream position."""
+    from pnp_svrg_amd import legacy_rng
+    for pool, size in ((np.array([0.5, 1.5, 2.5, 3.5]), 3), (np.array(7), 3), (6, np.int64(2)), (np.arange(5, dtype=np.uint8), 4)):
+        np.random.seed(11)
+        a = legacy_rng.choice(pool, size)
+        ua = np.random.uniform()
+        np.random.seed(11)
+        b = np.random.choice(pool, size, replace=False)
+        ub = np.random.uniform()
+        assert np.array_equal(a, b) and ua == ub
+        assert a.dtype == b.dtype or np.asarray(pool).dtype.kind in 'iu'        # (integer pools: int64, NumPy's default int)
+    with pytest.raises(ValueError):
+        legacy_rng.choice(np.zeros((2, 2), int), 1)
+    with pytest.raises(ValueError):
+        legacy_rng.choice(3, 5)

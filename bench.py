@@ -71,6 +71,7 @@ def parse():
                     help='conv kernel of the DnCNN prox (default: f32-winograd44 = F(4x4,3x3), or PNP_DNCNN_WINOGRAD; f32-winograd = F(2,3) along x, '
                          'f32-direct = implicit GEMM, bit for bit an fmaf chain)')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
+    ap.add_argument('--no-outer-kernel', action='store_true', help='A/B: config 2 as one launch per inner iteration instead of one per outer iteration')
     ap.add_argument('--no-fold', action='store_true', help='A/B: the outer full-gradient refresh as launches of its own instead of '
                                                             'folded into the first inner iteration (one-kernel iteration only)')
     ap.add_argument('--cpu-baseline-child', default=None, metavar='WORKLOAD:SECONDS', help=argparse.SUPPRESS)
@@ -196,11 +197,19 @@ class Workload:
         self.idx = self.batch.draw_minibatches(self.n_draw, self.mbsize, seed=7)
 
     def run(self, n):
+        eng = self.eng
+        # config 2: whole outer iterations as ONE launch each (the workgroup that owns a problem runs its T2 inner iterations back
+        # to back, pnp_csmri_svrg_outer_iteration) whenever the request is for whole outer iterations
+        if (self.idx is None and not getattr(self.a, 'no_outer_kernel', False) and hasattr(eng, 'outer_kernel_ok') and eng.outer_kernel_ok()
+                and n % T2 == 0 and eng.s % T2 == 0):
+            eng.run_outer(n // T2)
+            self.done += n
+            return
         for _ in range(n):
             if self.idx is not None:
-                self.eng.step(self.idx[self.done % self.n_draw])
+                eng.step(self.idx[self.done % self.n_draw])
             else:
-                self.eng.step()
+                eng.step()
             self.done += 1
 
     def roofline(self, dt_step):
@@ -466,6 +475,8 @@ def main():
     w = Workload(a.workload, B, rank, a, weights)
     if a.host_minibatches:
         w.predraw(a.steps + a.warmup)
+    if a.workload == 'tv' and not a.host_minibatches and a.steps % T2 == 0:
+        a.warmup = -(-max(a.warmup, 1) // T2) * T2               # whole outer iterations: the timed ones then run one launch each
     if a.graph:
         assert w.idx is None and a.workload != 'saga-nlm', '--graph needs device-side minibatch draws and the SVRG engine'
         a.steps = -(-a.steps // T2) * T2

@@ -129,6 +129,20 @@ int pnp_csmri_svrg_outer_step(pnp_csmri_plan* plan, const void* z, const uint32_
                               double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out,
                               void* sigma_out, void* stream);
 
+/* A whole OUTER iteration of the SVRG loop with the TV prox -- algorithms/pnp_svrg.py:32-95 for T2 inner iterations: the refresh
+ * mu = grad_full(z), w = z, then T2 times { minibatch SVRG direction, step, estimate_sigma, TVDenoiser.denoise, PSNR } -- in ONE
+ * launch: the workgroup that owns a problem runs pnp_csmri_svrg_outer_step and then T2 - 1 times pnp_csmri_svrg_step (a = z,
+ * b = w, c1 = z, c2 = mu, alpha = -lr / mini_batch_size, beta = 1, gamma = -lr, out = z) on THAT problem back to back; the
+ * results are bit for bit those of the T2 separate calls.  z is updated in place, w and mu are outputs.
+ *   selbits  [T2][batch][W][H/32]: slot j = the selector of inner iteration j (pnp_csmri_draw_thresholds' layout; slot 0 is
+ *            not read: at j = 0 the minibatch difference is exactly zero);
+ *   sse_log  [n_log][batch] double: inner iteration j writes row (log_row0 + j) % n_log (sum (xrec - z)^2 after its prox);
+ *   sigma_out [batch]: the noise estimate of the last inner iteration.                                        */
+int pnp_csmri_svrg_outer_iteration(pnp_csmri_plan* plan, void* z, void* w, void* mu, const uint32_t* mask_bitsT, const void* yh,
+                                   const void* alpha_vec, const uint32_t* selbits, int T2, double lr, int mini_batch_size,
+                                   double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_log,
+                                   int log_row0, int n_log, void* sigma_out, void* stream);
+
 /* ------------------------------------------------------------------ Deblur / super-resolution
  * Replaces problems/DeblurSR.py:119-147: 1-D circular blur of the raveled image via a length-H*W FFT
  * (spectrum of the kernel computed once at plan creation), optional 4-tap bilinear down-sampler

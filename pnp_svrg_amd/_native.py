@@ -35,6 +35,7 @@ SIGNATURES = {
     'pnp_csmri_grad_sel': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _d, _vp, _vp, _vp]),
     'pnp_csmri_svrg_step': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _d, _vp, _d, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp]),
     'pnp_csmri_svrg_outer_step': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp]),
+    'pnp_csmri_svrg_outer_iteration': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _i, _d, _d, _vp, _vp, _i, _i, _vp, _vp]),
     'pnp_deblur_plan_create': (_i, [ctypes.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     'pnp_deblur_plan_destroy': (_i, [_vp]),
     'pnp_deblur_grad': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp]),

@@ -436,6 +436,10 @@ int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* 
                        double alpha, const void* alpha_vec, double beta, const void* c1, double gamma, const void* c2, void* out,
                        int mode, double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_out, void* sigma_out,
                        void* stream, void* w_out = nullptr, void* mu_out = nullptr);
+int csmri_fused_outer_launch(int batch, const void* twtab, void* z, void* w, void* mu, const uint32_t* mask_bits, const void* yh,
+                             const void* alpha_vec, const uint32_t* selbits, int T2, double lr, int mini_batch_size,
+                             double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_log, int log_row0, int n_log,
+                             void* sigma_out, void* stream);
 }
 
 namespace {
@@ -517,4 +521,17 @@ extern "C" int pnp_csmri_svrg_outer_step(pnp_csmri_plan* p, const void* z, const
     PNP_CHECK_ARG(w_out != z && mu_out != z && w_out != mu_out && w_out != out && mu_out != out, "w_out and mu_out must be buffers of their own");
     return csmri_fused_launch(p->batch, p->twtab, z, nullptr, mask_bitsT, yh, 1.0, alpha_vec, 1.0, z, -lr, nullptr, out,
                               denoise ? 0 : 1, sigma_modifier, fallback_sigma, xrec, sse_out, sigma_out, stream, w_out, mu_out);
+}
+
+// ---- a whole outer iteration (refresh + T2 inner iterations, TV prox) in one launch
+extern "C" int pnp_csmri_svrg_outer_iteration(pnp_csmri_plan* p, void* z, void* w, void* mu, const uint32_t* mask_bitsT, const void* yh,
+                                              const void* alpha_vec, const uint32_t* selbits, int T2, double lr, int mini_batch_size,
+                                              double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_log,
+                                              int log_row0, int n_log, void* sigma_out, void* stream) {
+    PNP_CHECK_ARG(p && z && w && mu && mask_bitsT && yh && alpha_vec && xrec && sse_log && sigma_out, "null argument");
+    PNP_CHECK_ARG(p->dtype == PNP_F32 && p->H == 256 && p->W == 256, "the one-kernel iteration exists for f32 plans of 256 x 256");
+    PNP_CHECK_ARG(T2 >= 1 && (T2 == 1 || selbits != nullptr) && mini_batch_size >= 1 && n_log >= 1 && log_row0 >= 0, "bad T2 / selbits / mini_batch_size / log");
+    PNP_CHECK_ARG(z != w && z != mu && w != mu, "z, w and mu must be buffers of their own");
+    return csmri_fused_outer_launch(p->batch, p->twtab, z, w, mu, mask_bitsT, yh, alpha_vec, selbits, T2, lr, mini_batch_size,
+                                    sigma_modifier, fallback_sigma, xrec, sse_log, log_row0, n_log, sigma_out, stream);
 }

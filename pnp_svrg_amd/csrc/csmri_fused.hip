@@ -336,11 +336,11 @@ template <bool OUTER = false, int NOPS = 2>
 __device__ __forceinline__ void fused_gradient(RImg& R, const float* a, const float* b,
                                                const uint32_t* __restrict__ bits, const cx<float>* __restrict__ twtab, cx<float>* twl, cx<float>* ldc,
                                                uint32_t (*sbits)[FG][2][16], const cx<float>* __restrict__ yh, float scale, float beta,
-                                               const float* c1, float gamma, const float* c2, int g, int l,
+                                               const float* c1, float gamma, const float* c2, int t, int g, int l,
                                                float* w_out, float* mu_out PNP_STAMP_PARAM) {
     cx<float>* scr = ldc + g * F_SCR;
     float* ldf = reinterpret_cast<float*>(ldc);
-    const RLane L((int)threadIdx.x);
+    const RLane L(t);
     // selector bits of this group's four column pairs (two per half): fetched now, under the operand loads of phase 1 --
     // inside phase 2 their round trip to L2 sat exposed between two workgroup barriers, once per half
 #pragma unroll
@@ -353,7 +353,7 @@ __device__ __forceinline__ void fused_gradient(RImg& R, const float* a, const fl
             sbits[half][g][k][l] = bits[(size_t)(l < 8 ? ca : cb) * 8 + (l & 7)];
         }
     cx<float> twv = {0.f, 0.f};
-    if ((int)threadIdx.x < FN) twv = twtab[threadIdx.x];
+    if (t < FN) twv = twtab[t];
     cx<float> Z[FP][16];
     // ------------------------------------------------------------------ 1: operands in R, a - b, R -> F
     // Register budget (256 per lane): half an image of each operand is 64 registers.  Both operands of a half are requested
@@ -377,7 +377,7 @@ __device__ __forceinline__ void fused_gradient(RImg& R, const float* a, const fl
             if (H == 1) __syncthreads();                        // the first half's readers are done with the buffer
             r_to_f_write(A, ldf, L);
             if (H == 0) {
-                if ((int)threadIdx.x < FN) twl[threadIdx.x] = twv;   // twiddles: requested before the operands, landed with them
+                if (t < FN) twl[t] = twv;   // twiddles: requested before the operands, landed with them
                 gld_passes<4>(A, a, 4, L.voff);
                 if (b != nullptr) gld_passes<4>(Bv, b, 4, L.voff);
             }
@@ -564,48 +564,55 @@ namespace pnp {
 //       2 = the gradient only (phases 1-3: grad_full with its data term, or any other use of pnp_csmri_grad_sel that fits
 //           this kernel).
 enum { FUSED_FULL = 0, FUSED_NO_DENOISE = 1, FUSED_GRAD = 2 };
-template <int MODE, bool OUTER = false, int NOPS = 2>
-__global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b,
-                                                  const uint32_t* __restrict__ bitsT, const cx<float>* __restrict__ yh,
-                                                  const cx<float>* __restrict__ twtab,
-                                                  float scale, const float* __restrict__ alpha_vec, float beta, const float* c1,
-                                                  float gamma, const float* c2, float* out,
-                                                  float sigma_modifier, float fallback_sigma, const float* __restrict__ xrec,
-                                                  double* __restrict__ sse_out, float* __restrict__ sigma_out,
-                                                  float* w_out, float* mu_out, int stagger_n, int stagger_groups, int stagger_units) {
-    constexpr bool DENOISE = MODE == FUSED_FULL;
-    // De-synchronisation of the CUs.  Every workgroup does the same work, so the 256 CUs of a launch march through the phases in
-    // lock step: during the three memory phases ALL of them pull on HBM (saturated, ~10 B/clk per CU), during the compute phases
-    // none does (in-kernel clock stamps: the memory phases take the same time whether loads are 4 or 16 bytes wide).  The first
-    // workgroup of every CU (the first `stagger_n` of the grid) therefore starts (blockIdx % groups) * units * 1024 cycles
-    // late; the offsets persist through the later workgroups of the launch, and one group's memory phases meet the others'
-    // transforms.
+// the LDS a workgroup needs beside the 132 KB hand-over buffer
+struct FusedShared {
+    cx<float> twl[FN];
+    uint32_t sbits[2][FG][2][16];
+    double red[8];
+    float sig_sh;
+};
+
+// De-synchronisation of the CUs.  Every workgroup does the same work, so the 256 CUs of a launch march through the phases in
+// lock step: during the three memory phases ALL of them pull on HBM (saturated, ~10 B/clk per CU), during the compute phases
+// none does (in-kernel clock stamps: the memory phases take the same time whether loads are 4 or 16 bytes wide).  The first
+// workgroup of every CU (the first `stagger_n` of the grid) therefore starts (blockIdx % groups) * units * 1024 cycles
+// late; the offsets persist through the later workgroups of the launch, and one group's memory phases meet the others'
+// transforms.
+__device__ __forceinline__ void startup_stagger(int stagger_n, int stagger_groups, int stagger_units) {
     if (stagger_units > 0 && (int)blockIdx.x < stagger_n) {
         const int n = ((int)blockIdx.x % stagger_groups) * stagger_units;
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
     }
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+}
+
+// One whole iteration of one image (`a` ... `out`, `xrec`, `w_out`, `mu_out`: THIS image's arrays; sse_out / sigma_out: this
+// image's slots).  Whole-workgroup collective.
+template <int MODE, bool OUTER, int NOPS>
+__device__ __forceinline__ void svrg_iter_body(unsigned char* lds_raw, FusedShared& sh, const float* a, const float* b,
+                                               const uint32_t* __restrict__ bits, const cx<float>* __restrict__ yh,
+                                               const cx<float>* __restrict__ twtab, float scale, float beta, const float* c1,
+                                               float gamma, const float* c2, float* oi, float sigma_modifier, float fallback_sigma,
+                                               const float* xri, double* __restrict__ sse_out, float* __restrict__ sigma_out,
+                                               float* w_out, float* mu_out) {
+    constexpr bool DENOISE = MODE == FUSED_FULL;
     cx<float>* ldc = reinterpret_cast<cx<float>*>(lds_raw);
     float* ldf = reinterpret_cast<float*>(lds_raw);
-    __shared__ cx<float> twl[FN];
-    __shared__ uint32_t sbits[2][FG][2][16];
-    __shared__ double red[8];
-    __shared__ float sig_sh;
-    const int t = threadIdx.x, g = t >> 4, l = t & 15, wv = t >> 6, lane64 = t & 63;
-    const int prob = blockIdx.x;
-    const size_t img = (size_t)prob * FN * FN;
-    // (the twiddle table goes to LDS inside fused_gradient, under the operand loads of phase 1)
-    if (alpha_vec != nullptr) scale *= alpha_vec[prob];
+    cx<float>* twl = sh.twl;
+    uint32_t (*sbits)[FG][2][16] = sh.sbits;
+    double* red = sh.red;
+    float& sig_sh = sh.sig_sh;
+    // (laundered: called from a loop -- k_svrg_outer -- hipcc would otherwise hoist every lane-dependent address and every
+    //  per-pass base out of the loop and keep them alive across the whole body: 86 scalar and 265 vector registers spilled)
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    asm volatile("" : "+s"(a), "+s"(b), "+s"(bits), "+s"(yh), "+s"(c1), "+s"(c2), "+s"(oi), "+s"(xri), "+s"(w_out), "+s"(mu_out));
+    const int g = t >> 4, l = t & 15, wv = t >> 6, lane64 = t & 63;
 
     PNP_STAMP_DECL;
     PNP_STAMP(0);
     const RLane L(t);
     RImg R;
-    fused_gradient<OUTER, NOPS>(R, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8, twtab, twl, ldc, sbits,
-                          yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, scale, beta,
-                          c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, g, l,
-                          OUTER ? w_out + img : nullptr, OUTER ? mu_out + img : nullptr PNP_STAMP_ARG);
-    float* oi = out + img;
+    fused_gradient<OUTER, NOPS>(R, a, b, bits, twtab, twl, ldc, sbits, yh, scale, beta, c1, gamma, c2, t, g, l, w_out, mu_out PNP_STAMP_ARG);
     if (MODE == FUSED_GRAD) {
         gst_passes<8>(oi, 0, L.voff, R);
         return;
@@ -632,7 +639,6 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     PNP_STAMP(6);
 
     // ------------------------------------------------------------------ 5: noise estimate, prox, C -> R, error, store
-    const float* xri = xrec != nullptr ? xrec + img : nullptr;
     const bool want_err = DENOISE && xri != nullptr;
     // sigma_est = mean over the 256 columns of the per-column MAD estimate
     {
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
     }
     const float sigma_est = sig_sh;
     PNP_STAMP(7);
-    if (sigma_out != nullptr && t == 0) sigma_out[prob] = sigma_est;
+    if (sigma_out != nullptr && t == 0) *sigma_out = sigma_est;
     if (DENOISE) {
         const float sigma = sigma_est > 0.f ? sigma_est * sigma_modifier : fallback_sigma;
         haar_bayes_shrink<float, FN>(x[0], sigma * sigma);
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
         if (t == 0) {
             double s = 0;
             for (int i = 0; i < FT / 64; ++i) s += red[i];
-            sse_out[prob] = s;
+            *sse_out = s;
         }
     }
 #ifdef PNP_FUSED_CLOCK
@@ -731,6 +737,125 @@ __global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b
 #endif
     PNP_STAMP(9);
     PNP_STAMP_FLUSH;
+}
+
+// MODE: 0 = the whole iteration; 1 = stop after the noise estimate and store the stepped image (another prox follows);
+//       2 = the gradient only.  OUTER: the outer refresh folded in.  NOPS: epilogue operand arrays present.
+template <int MODE, bool OUTER = false, int NOPS = 2>
+__global__ __launch_bounds__(FT) void k_svrg_iter(const float* a, const float* b,
+                                                  const uint32_t* __restrict__ bitsT, const cx<float>* __restrict__ yh,
+                                                  const cx<float>* __restrict__ twtab,
+                                                  float scale, const float* __restrict__ alpha_vec, float beta, const float* c1,
+                                                  float gamma, const float* c2, float* out,
+                                                  float sigma_modifier, float fallback_sigma, const float* __restrict__ xrec,
+                                                  double* __restrict__ sse_out, float* __restrict__ sigma_out,
+                                                  float* w_out, float* mu_out, int stagger_n, int stagger_groups, int stagger_units) {
+    startup_stagger(stagger_n, stagger_groups, stagger_units);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ FusedShared sh;
+    const int prob = blockIdx.x;
+    const size_t img = (size_t)prob * FN * FN;
+    if (alpha_vec != nullptr) scale *= alpha_vec[prob];
+    svrg_iter_body<MODE, OUTER, NOPS>(lds_raw, sh, a + img, b != nullptr ? b + img : nullptr, bitsT + (size_t)prob * FN * 8,
+                                      yh != nullptr ? yh + (size_t)prob * (FN / 2) * FN : nullptr, twtab, scale, beta,
+                                      c1 != nullptr ? c1 + img : nullptr, gamma, c2 != nullptr ? c2 + img : nullptr, out + img,
+                                      sigma_modifier, fallback_sigma, xrec != nullptr ? xrec + img : nullptr,
+                                      sse_out != nullptr ? sse_out + prob : nullptr, sigma_out != nullptr ? sigma_out + prob : nullptr,
+                                      OUTER ? w_out + img : nullptr, OUTER ? mu_out + img : nullptr);
+}
+
+// A whole OUTER iteration of pnp_svrg with the TV prox in one launch (algorithms/pnp_svrg.py:32-95 for T2 inner iterations): the
+// workgroup that owns an image runs the folded refresh + first inner iteration and then the T2 - 1 plain inner iterations of
+// THAT image back to back.  Inner iterations of different images never meet, so there is nothing to synchronise across
+// workgroups; between two iterations of one image the data goes through memory (z, w, mu are written and read by the very
+// same lanes, in the R layout) -- one s_waitcnt and an L1 invalidate.  What it buys over T2 launches: no launch tails, the
+// start-up stagger paid once per T2 rounds, and the operands an image re-reads every iteration (w, mu, the ground truth, z)
+// come back while only the 256 images in flight compete for the caches, not the whole batch.
+// selbits: [T2][batch][W][H/32] (slot j = inner iteration j; slot 0 is not read), sse_log: [n_log][batch], row (log_row0 + j) % n_log.
+__global__ __launch_bounds__(FT) void k_svrg_outer(float* z, float* w, float* mu, const uint32_t* __restrict__ mask_bits,
+                                                   const cx<float>* __restrict__ yh, const float* __restrict__ alpha_vec,
+                                                   const uint32_t* __restrict__ selbits, int T2, float scale_inner, float gamma,
+                                                   const cx<float>* __restrict__ twtab, float sigma_modifier, float fallback_sigma,
+                                                   const float* __restrict__ xrec, double* __restrict__ sse_log, int log_row0, int n_log,
+                                                   float* __restrict__ sigma_out, int stagger_n, int stagger_groups, int stagger_units) {
+    startup_stagger(stagger_n, stagger_groups, stagger_units);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ FusedShared sh;
+    const int prob = blockIdx.x, batch = gridDim.x;
+    const size_t img = (size_t)prob * FN * FN;
+    const float inv_n = 1.0f / ((float)FN * (float)FN);
+    float* zi = z + img;
+    // outer refresh + inner iteration 0 (pnp_csmri_svrg_outer_step)
+    svrg_iter_body<FUSED_FULL, true, 0>(lds_raw, sh, zi, nullptr, mask_bits + (size_t)prob * FN * 8, yh + (size_t)prob * (FN / 2) * FN, twtab,
+                                        inv_n * alpha_vec[prob], 1.0f, zi, gamma, nullptr, zi, sigma_modifier, fallback_sigma, xrec + img,
+                                        sse_log + (size_t)(log_row0 % n_log) * batch + prob, sigma_out + prob, w + img, mu + img);
+#pragma unroll 1
+    for (int j = 1; j < T2; ++j) {
+        // this iteration reads what the last one wrote (same lanes, same addresses): stores done, no stale line in the L1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        svrg_iter_body<FUSED_FULL, false, 2>(lds_raw, sh, zi, w + img, selbits + ((size_t)j * batch + prob) * FN * 8, nullptr, twtab,
+                                             scale_inner, 1.0f, zi, gamma, mu + img, zi, sigma_modifier,
+                                             fallback_sigma, xrec + img, sse_log + (size_t)((log_row0 + j) % n_log) * batch + prob,
+                                             sigma_out + prob, nullptr, nullptr);
+    }
+}
+
+// stagger (see startup_stagger): only launches of more than one workgroup per CU pay for it and profit from it
+static int stagger_config(int* num_cu_out, int* groups, int* units) {
+    static int num_cu = 0, st_groups = 2, st_units = 40;    // same-box sweep (tools/dev/stagger_sweep.py): 0.588 ms per config-2 step without, 0.575 with (2, 40), slower from (8, 20) on
+    if (num_cu == 0) {
+        int d0 = 0;
+        hipDeviceProp_t prop;
+        PNP_CHECK_HIP(hipGetDevice(&d0));
+        PNP_CHECK_HIP(hipGetDeviceProperties(&prop, d0));
+        if (const char* ev = getenv("PNP_FUSED_STAGGER")) {   // "groups,units" (A/B timing); "0" switches it off
+            int g = 0, u = 0;
+            if (sscanf(ev, "%d,%d", &g, &u) == 2 && g >= 1 && u >= 0) { st_groups = g; st_units = u; }
+            else st_units = 0;
+        }
+        num_cu = prop.multiProcessorCount;
+    }
+    *num_cu_out = num_cu; *groups = st_groups; *units = st_units;
+    return PNP_OK;
+}
+
+static int fused_lds_optin() {
+    // > 64 KiB of dynamic LDS needs the opt-in, once per device (the attribute is per device)
+    static unsigned long long attr_done = 0;
+    int dev = 0;
+    PNP_CHECK_HIP(hipGetDevice(&dev));
+    if (!((attr_done >> (dev & 63)) & 1ull)) {
+#define PNP_FUSED_ATTR(...) PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES))
+        PNP_FUSED_ATTR(0, false, 0); PNP_FUSED_ATTR(0, false, 1); PNP_FUSED_ATTR(0, false, 2);
+        PNP_FUSED_ATTR(1, false, 0); PNP_FUSED_ATTR(1, false, 1); PNP_FUSED_ATTR(1, false, 2);
+        PNP_FUSED_ATTR(2, false, 0); PNP_FUSED_ATTR(2, false, 1); PNP_FUSED_ATTR(2, false, 2);
+        PNP_FUSED_ATTR(0, true, 0); PNP_FUSED_ATTR(1, true, 0);
+#undef PNP_FUSED_ATTR
+        PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_outer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES));
+        attr_done |= 1ull << (dev & 63);
+    }
+    return PNP_OK;
+}
+
+// one launch = one outer iteration (k_svrg_outer); scales computed exactly as the per-iteration entry points compute them
+int csmri_fused_outer_launch(int batch, const void* twtab, void* z, void* w, void* mu, const uint32_t* mask_bits, const void* yh,
+                             const void* alpha_vec, const uint32_t* selbits, int T2, double lr, int mini_batch_size,
+                             double sigma_modifier, double fallback_sigma, const void* xrec, double* sse_log, int log_row0, int n_log,
+                             void* sigma_out, void* stream) {
+    int num_cu = 0, st_groups = 0, st_units = 0;
+    { const int rc = stagger_config(&num_cu, &st_groups, &st_units); if (rc != PNP_OK) return rc; }
+    { const int rc = fused_lds_optin(); if (rc != PNP_OK) return rc; }
+    const double alpha = -lr / (double)mini_batch_size;
+    const float scale_inner = (float)(alpha / ((double)FN * (double)FN));
+    k_svrg_outer<<<batch, FT, F_LDS_BYTES, (hipStream_t)stream>>>((float*)z, (float*)w, (float*)mu, mask_bits, (const cx<float>*)yh,
+                                                                 (const float*)alpha_vec, selbits, T2, scale_inner, (float)(-lr),
+                                                                 (const cx<float>*)twtab, (float)sigma_modifier, (float)fallback_sigma,
+                                                                 (const float*)xrec, sse_log, log_row0, n_log, (float*)sigma_out, num_cu,
+                                                                 st_groups, 0);     // (no stagger: same-box A/B 0.539 ms per step without, 0.546 with (2, 40))
+    PNP_CHECK_LAUNCH();
+    return PNP_OK;
 }
 
 // plan internals live in csmri.hip (pnp_csmri_svrg_step / pnp_csmri_grad_sel); the kernel only needs the plan's twiddle table.
@@ -741,38 +866,14 @@ int csmri_fused_launch(int batch, const void* twtab, const void* a, const void* 
                        void* stream, void* w_out, void* mu_out) {
     const float scale = (float)(alpha / ((double)FN * (double)FN));
     hipStream_t s = (hipStream_t)stream;
-    // stagger (see the kernel): only launches of more than one workgroup per CU pay for it and profit from it
-    static int num_cu = 0, st_groups = 2, st_units = 40;    // same-box sweep (tools/dev/stagger_sweep.py): 0.588 ms per config-2 step without, 0.575 with (2, 40), slower from (8, 20) on
-    if (num_cu == 0) {
-        int d0 = 0;
-        hipDeviceProp_t prop;
-        PNP_CHECK_HIP(hipGetDevice(&d0));
-        PNP_CHECK_HIP(hipGetDeviceProperties(&prop, d0));
-        num_cu = prop.multiProcessorCount;
-        if (const char* ev = getenv("PNP_FUSED_STAGGER")) {   // "groups,units" (A/B timing); "0" switches it off
-            int g = 0, u = 0;
-            if (sscanf(ev, "%d,%d", &g, &u) == 2 && g >= 1 && u >= 0) { st_groups = g; st_units = u; }
-            else st_units = 0;
-        }
-    }
+    int num_cu = 0, st_groups = 0, st_units = 0;
+    { const int rc = stagger_config(&num_cu, &st_groups, &st_units); if (rc != PNP_OK) return rc; }
     const int stagger_units = batch > num_cu ? st_units : 0;
-    // > 64 KiB of dynamic LDS needs the opt-in, once per device (the attribute is per device)
-    static unsigned long long attr_done = 0;
-    int dev = 0;
-    PNP_CHECK_HIP(hipGetDevice(&dev));
+    { const int rc = fused_lds_optin(); if (rc != PNP_OK) return rc; }
     // epilogue operands as the kernel takes them: (c1, beta) first, then (c2, gamma); a lone c2 moves to the first slot
     int nops = (c1 != nullptr ? 1 : 0) + (c2 != nullptr ? 1 : 0);
     if (c1 == nullptr && c2 != nullptr) { c1 = c2; beta = gamma; c2 = nullptr; }
     const bool outer = w_out != nullptr;
-    if (!((attr_done >> (dev & 63)) & 1ull)) {
-#define PNP_FUSED_ATTR(...) PNP_CHECK_HIP(hipFuncSetAttribute((const void*)k_svrg_iter<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES))
-        PNP_FUSED_ATTR(0, false, 0); PNP_FUSED_ATTR(0, false, 1); PNP_FUSED_ATTR(0, false, 2);
-        PNP_FUSED_ATTR(1, false, 0); PNP_FUSED_ATTR(1, false, 1); PNP_FUSED_ATTR(1, false, 2);
-        PNP_FUSED_ATTR(2, false, 0); PNP_FUSED_ATTR(2, false, 1); PNP_FUSED_ATTR(2, false, 2);
-        PNP_FUSED_ATTR(0, true, 0); PNP_FUSED_ATTR(1, true, 0);
-#undef PNP_FUSED_ATTR
-        attr_done |= 1ull << (dev & 63);
-    }
 #define PNP_FUSED_LAUNCH(...)                                                                                             \
     k_svrg_iter<__VA_ARGS__><<<batch, FT, F_LDS_BYTES, s>>>((const float*)a, (const float*)b, bitsT, (const cx<float>*)yh,    \
                                                        (const cx<float>*)twtab, scale, (const float*)alpha_vec, (float)beta,    \

@@ -115,32 +115,57 @@ constexpr int kSmallBatch = 32;                                // up to this man
 struct SmallProxScratch { void* sig_cols; double* partial; unsigned* counter; };
 
 // scratch of the split form, one set per (device, stream) -- two streams running a small-batch prox at the same time would
-// otherwise race on sig_cols and on the last-workgroup counter, and a captured graph bakes these pointers in, so
-// they are never freed or moved.  Allocated on first use (never inside a hipGraph capture: captured callers run one eager
-// warm-up call first, as every graph in this code base does); an entry is committed only once all of it exists.
+// otherwise race on sig_cols and on the last-workgroup counter.  Nothing can be allocated while a stream is being
+// captured, and a capture stream is a new stream: a CAPTURED call takes the device's default set, which every eager call makes
+// sure exists (captured callers run one eager warm-up call first, as every graph in this code base does) -- graphs of one
+// device therefore share a set and must not be replayed concurrently on two streams.  Sets are never freed or moved (graphs
+// bake the pointers in); an entry is committed only once all of it exists.
 static int small_prox_scratch(SmallProxScratch** out, hipStream_t stream) {
     struct Entry { int dev; hipStream_t stream; SmallProxScratch s; };
     static std::vector<Entry*> tab;
     static std::mutex mu;
+    static const hipStream_t kDefault = (hipStream_t)(intptr_t)-1;
     int dev = 0;
     PNP_CHECK_HIP(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream != nullptr) (void)hipStreamIsCapturing(stream, &cap);
     std::lock_guard<std::mutex> lock(mu);
-    for (Entry* e : tab)
-        if (e->dev == dev && e->stream == stream) { *out = &e->s; return PNP_OK; }
-    SmallProxScratch n = {};
-    hipError_t err = hipMalloc(&n.sig_cols, (size_t)kSmallBatch * 256 * sizeof(double));
-    if (err == hipSuccess) err = hipMalloc((void**)&n.partial, (size_t)kSmallBatch * 16 * sizeof(double));
-    if (err == hipSuccess) err = hipMalloc((void**)&n.counter, (size_t)kSmallBatch * sizeof(unsigned));
-    if (err == hipSuccess) err = hipMemset(n.counter, 0, (size_t)kSmallBatch * sizeof(unsigned));
-    if (err != hipSuccess) {
-        if (n.sig_cols) (void)hipFree(n.sig_cols);
-        if (n.partial) (void)hipFree(n.partial);
-        if (n.counter) (void)hipFree(n.counter);
-        set_error(std::string("small_prox_scratch: ") + hipGetErrorString(err));
-        return PNP_ERR_HIP;
+    auto find = [&](hipStream_t st) -> SmallProxScratch* {
+        for (Entry* e : tab)
+            if (e->dev == dev && e->stream == st) return &e->s;
+        return nullptr;
+    };
+    auto create = [&](hipStream_t st, SmallProxScratch** res) -> int {
+        SmallProxScratch n = {};
+        hipError_t err = hipMalloc(&n.sig_cols, (size_t)kSmallBatch * 256 * sizeof(double));
+        if (err == hipSuccess) err = hipMalloc((void**)&n.partial, (size_t)kSmallBatch * 16 * sizeof(double));
+        if (err == hipSuccess) err = hipMalloc((void**)&n.counter, (size_t)kSmallBatch * sizeof(unsigned));
+        if (err == hipSuccess) err = hipMemset(n.counter, 0, (size_t)kSmallBatch * sizeof(unsigned));
+        if (err != hipSuccess) {
+            if (n.sig_cols) (void)hipFree(n.sig_cols);
+            if (n.partial) (void)hipFree(n.partial);
+            if (n.counter) (void)hipFree(n.counter);
+            set_error(std::string("small_prox_scratch: ") + hipGetErrorString(err));
+            return PNP_ERR_HIP;
+        }
+        tab.push_back(new Entry{dev, st, n});
+        *res = &tab.back()->s;
+        return PNP_OK;
+    };
+    if (cap != hipStreamCaptureStatusNone) {
+        SmallProxScratch* d = find(kDefault);
+        if (d == nullptr) {
+            set_error("small_prox_scratch: a small-batch prox was captured in a hipGraph before any eager call on this device (run one eager warm-up call first)");
+            return PNP_ERR_HIP;
+        }
+        *out = d;
+        return PNP_OK;
     }
-    tab.push_back(new Entry{dev, stream, n});
-    *out = &tab.back()->s;
+    SmallProxScratch* d = find(kDefault);
+    if (d == nullptr) { const int rc = create(kDefault, &d); if (rc != PNP_OK) return rc; }
+    SmallProxScratch* e = find(stream);
+    if (e == nullptr) { const int rc = create(stream, &e); if (rc != PNP_OK) return rc; }
+    *out = e;
     return PNP_OK;
 }
 

@@ -700,8 +700,33 @@ class SvrgEngine(_StochEngine):
             self.step_dev.fill_(s)
             self._dev_step = s
 
-    def run_outer(self, n_outer=1):
-        """n_outer graph replays = n_outer * T2 inner iterations."""
+    def outer_kernel_ok(self):
+        """Whether whole outer iterations can run as ONE launch each (pnp_csmri_svrg_outer_iteration): the one-kernel iteration
+        with the prox inside it (TV, no host-side per-call state), the outer refresh folded in, device-drawn minibatches."""
+        return (self.fused and self.fold_outer and self.variant == 'svrg' and getattr(self.prox, 'fused_denoise', False)
+                and getattr(self.prox, 'denoise_strength', 0.0) == 0.0 and all(h is None for h in self.mbs.host))
+
+    def run_outer(self, n_outer=1, one_launch=None):
+        """n_outer outer iterations = n_outer * T2 inner iterations, from a step count that is a multiple of T2.
+        one_launch (default: when `outer_kernel_ok()`): every outer iteration is ONE draw launch + ONE kernel in which the
+        workgroup that owns a problem runs its T2 inner iterations back to back -- the same bits as stepping; otherwise
+        replays of the captured hipGraph."""
+        if one_launch is None:
+            one_launch = self.outer_kernel_ok()
+        if one_launch:
+            if not self.outer_kernel_ok() or self.s % self.T2 != 0 or self.n_prox != self.s:
+                raise ValueError('one launch per outer iteration needs the one-kernel iteration with the TV prox, the folded '
+                                 'refresh, device-drawn minibatches and a step count that is a multiple of T2')
+            b, px = self.b, self.prox
+            for _ in range(n_outer):
+                b.draw(self.mbs, self.mb, self.seed, self.s, self.T2)
+                lr = self.eta * self.lr_decay ** (self.s // self.T2)
+                b.plan.svrg_outer_iteration(self.z, self.w, self.mu, b.bits, b.yh_full, b.inv_m0, self.mbs.selbits, self.T2, lr, self.mb,
+                                            b.xrec, self.sse_log, self.n_prox % self.n_log, px.sig, sigma_modifier=px.sigma_modifier)
+                self.s += self.T2
+                self.n_prox += self.T2
+                px.t += self.T2
+            return
         if self.graph is None:
             self.capture()
         self._set_dev_step(self.s)

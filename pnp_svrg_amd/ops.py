@@ -150,6 +150,19 @@ class CsmriPlan:
         return out, sse, sigma_out
 
 
+    def svrg_outer_iteration(self, z, w, mu, mask_bits, yh, alpha_vec, selbits, T2, lr, mini_batch_size, xrec, sse_log, log_row0,
+                             sigma_out, *, sigma_modifier=1.0, fallback_sigma=0.0):
+        """pnp_csmri_svrg_outer_iteration: refresh + T2 inner iterations with the TV prox in ONE launch (z in place; w, mu out)."""
+        assert self.dtype == torch.float32 and self.H == 256 and self.W == 256
+        for t in (z, w, mu, xrec):
+            assert t.dtype == self.dtype and t.numel() == self.B * self.H * self.W
+        assert selbits.dtype == torch.int32 and tuple(selbits.shape) == (T2, self.B, self.W, self.H // 32)
+        assert sse_log.dtype == torch.float64 and sse_log.dim() == 2 and sse_log.shape[1] == self.B and sse_log.is_contiguous()
+        N.call('pnp_csmri_svrg_outer_iteration', self._h, _p(z), _p(w), _p(mu), _p(mask_bits), _p(yh), _p(alpha_vec), _p(selbits), int(T2),
+               float(lr), int(mini_batch_size), float(sigma_modifier), float(fallback_sigma), _p(xrec), _p(sse_log), int(log_row0),
+               int(sse_log.shape[0]), _p(sigma_out), _stream())
+
+
 class DncnnPlan:
     """pnp_dncnn_plan_*: DnCNN-17 prox for B images of H x W (fp32 network on the f32 matrix cores).
 

@@ -542,3 +542,32 @@ def test_folded_outer_refresh_is_bit_identical(prox_kind, monkeypatch):
     for s in range(T2 + 1):
         h1.step(idx[s]); h2.step(idx[s])
     assert torch.equal(h1.z, h2.z) and np.array_equal(h1.psnr_trace(), h2.psnr_trace())
+
+
+def test_outer_iteration_in_one_launch_is_bit_identical():
+    """pnp_csmri_svrg_outer_iteration (`SvrgEngine.run_outer`, one draw + ONE kernel per outer iteration: the workgroup that owns a
+    problem runs the folded refresh and its T2 inner iterations back to back) == the same iterations stepped one launch each:
+    identical iterate, w, mu, PSNR log and prox counter; across a wrap of the log ring; with a decaying step size."""
+    from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, TVProx
+    B, mb, T2 = 3, 1000, 4
+    batch = CsmriBatch.synthetic(B, 256, 256, 0.2, 20.0, seed=23)
+    for decay, n_log in ((1.0, 4096), (0.9, 6)):
+        e1 = SvrgEngine(batch, TVProx(sigma_modifier=1.2), 2e3, T2, mb, lr_decay=decay, seed=5, fused=True, n_log=n_log)
+        e2 = SvrgEngine(batch, TVProx(sigma_modifier=1.2), 2e3, T2, mb, lr_decay=decay, seed=5, fused=True, n_log=n_log)
+        assert e1.outer_kernel_ok()
+        e1.run_outer(3)
+        for _ in range(3 * T2):
+            e2.step()
+        assert e1.s == e2.s == 3 * T2 and e1.prox.t == e2.prox.t
+        assert torch.equal(e1.z, e2.z) and torch.equal(e1.w, e2.w) and torch.equal(e1.mu, e2.mu)
+        assert np.array_equal(e1.psnr_trace(), e2.psnr_trace())
+        assert torch.equal(e1.prox.sig, e2.prox.sig)
+        # and on: stepping continues from a one-launch run, a one-launch run from stepping
+        e1.step(); e2.step()
+        assert torch.equal(e1.z, e2.z)
+    with pytest.raises(ValueError):
+        e1.run_outer(1, one_launch=True)                        # 13 steps done: not a multiple of T2
+    # host-fed selectors cannot take this route
+    e3 = SvrgEngine(batch, TVProx(), 2e3, T2, mb, seed=5, fused=True)
+    e3.step(batch.draw_minibatches(1, mb, seed=2)[0])
+    assert not e3.outer_kernel_ok()

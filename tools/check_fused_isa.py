@@ -50,7 +50,7 @@ def kernels(txt):
     i = 0
     while i < len(lines):
         l = lines[i]
-        if l.startswith('_ZN3pnp11k_svrg_iter') and l.split(';')[0].rstrip().endswith(':'):
+        if l.startswith(('_ZN3pnp11k_svrg_iter', '_ZN3pnp12k_svrg_outer')) and l.split(';')[0].rstrip().endswith(':'):
             name = l.split(':')[0]
             body = []
             i += 1

@@ -237,9 +237,10 @@ class Workload:
             alg = TV_BYTES_PER_ITER * B
             ach = alg / dt_step / 1e9
             return {'bound': 'hbm',
-                    'kernel': 'whole inner iteration = pnp::k_svrg_iter (SVRG step through the masked FFT, noise estimate, Haar prox, error sum in '
-                              'one kernel, image register-resident, every global access 16 bytes per lane; the outer full-gradient refresh folded '
-                              'into the first inner iteration) + 1/T2 of k_draw_thr',
+                    'kernel': 'whole inner iteration = 1/T2 of pnp::k_svrg_outer (one launch per outer iteration: the workgroup that owns a problem '
+                              'runs the folded full-gradient refresh and its T2 inner iterations back to back; each iteration = SVRG step through the '
+                              'masked FFT, noise estimate, Haar prox, error sum, image register-resident, every global access 16 bytes per lane) '
+                              '+ 1/T2 of k_draw_thr; with --no-outer-kernel: one pnp::k_svrg_iter launch per inner iteration',
                     'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                     'traffic': _traffic(f'tv_step_B{B}')[0], 'traffic_source': _traffic(f'tv_step_B{B}')[1], 'bytes_per_step': alg}
         # saga-nlm: the NLM prox dominates (VALU-bound patch search); the table update is the HBM-bound part

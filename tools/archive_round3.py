@@ -28,10 +28,11 @@ for d, dst in (('tv_stats', f'{tag}_tv_kernel_stats.csv'), ('dncnn_stats', f'{ta
 # HBM traffic of a config-2 step: all kernels of the profiled steps, per problem-iteration
 bench = json.load(open(os.path.join(O, 'tv_f.json')))
 B, steps = bench['config']['batch_per_gpu'], bench['steps']
-lines = [f'# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --workload tv --steps {steps} --warmup 0 (B = {B})',
+lines = [f'# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --workload tv --steps {steps} --warmup 0 (B = {B}; the warm-up is rounded up to one outer iteration, so two outer iterations are counted)',
          '# counters are in KiB; gfx950: FETCH_SIZE is doubled for 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM section) -- the one-kernel iteration now',
          '# reads and writes 16 bytes per lane everywhere, the draw kernel 4 bytes per lane']
 tot = {}
+nouter = 0
 for ctr, d in (('FETCH_SIZE', 'tv_f'), ('WRITE_SIZE', 'tv_w')):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(newest(d + '/**/*counter_collection.csv'))):
@@ -41,13 +42,17 @@ for ctr, d in (('FETCH_SIZE', 'tv_f'), ('WRITE_SIZE', 'tv_w')):
             agg[k][1] += float(r['Counter_Value'])
     tot[ctr] = 0.0
     for k, (n, t) in sorted(agg.items()):
-        wide = 'k_svrg_iter' in k
+        wide = 'k_svrg_iter' in k or 'k_svrg_outer' in k
         corr = t * (2.0 if (ctr == 'FETCH_SIZE' and wide) else 1.0)
         lines.append(f'{ctr} {k:<40s} dispatches={n:4d} mean_KiB_raw={t / n:12.1f}' + ('  (x2 for 16-byte reads)' if ctr == 'FETCH_SIZE' and wide else ''))
-        if any(s in k for s in ('k_svrg_iter', 'k_draw_thr')):
+        if any(s in k for s in ('k_svrg_iter', 'k_svrg_outer', 'k_draw_thr')):
             tot[ctr] += corr
+        if 'k_svrg_outer' in k:
+            nouter = n
+if nouter:                                    # one k_svrg_outer launch = T2 = 10 inner iterations (bench.py rounds the warm-up up to whole outer iterations)
+    steps = 10 * nouter
 per = (tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024 / (B * steps)
-lines.append(f'config-2 step (k_svrg_iter incl. the folded outer refresh + k_draw_thr): {per / 1e6:.3f} MB per problem-iteration '
+lines.append(f'config-2 step (k_svrg_outer = folded outer refresh + T2 inner iterations per launch, + k_draw_thr): {per / 1e6:.3f} MB per problem-iteration '
              f'(fetch {tot["FETCH_SIZE"] * 1024 / (B * steps) / 1e6:.3f} + write {tot["WRITE_SIZE"] * 1024 / (B * steps) / 1e6:.3f}); algorithmic 2.425 MB (SURVEY 8d), physically needed 1.57 MB')
 open(os.path.join(P, f'{tag}_tv_pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
 tj = os.path.join(P, 'traffic.json')
@@ -55,18 +60,18 @@ t = json.load(open(tj)) if os.path.exists(tj) else {}
 t[f'tv_step_B{B}'] = per * B
 t[f'tv_step_B{B}_source'] = f'profiles/{tag}_tv_pmc_summary.txt (builder PMC run, not measured by the run that prints this line)'
 json.dump(t, open(tj, 'w'), indent=1)
-# SQ counters of k_svrg_iter<0, false, 2>
+# SQ counters of k_svrg_outer
 vals = collections.defaultdict(list)
 for d in ('tv_sq1', 'tv_sq2'):
     f = newest(d + '/**/*counter_collection.csv')
     if not f:
         continue
     for r in csv.DictReader(open(f)):
-        if 'k_svrg_iter<0, false, 2>' in r['Kernel_Name'] or 'k_svrg_iterILi0ELb0ELi2' in r['Kernel_Name']:
+        if 'k_svrg_outer' in r['Kernel_Name']:
             vals[r['Counter_Name']].append(float(r['Counter_Value']))
 if vals:
     m = {k: sum(v) / len(v) for k, v in vals.items()}
-    out = ['# rocprofv3 --kernel-trace --pmc <SQ counters> (two passes; tools/prof_round3.sh) -- bench.py --workload tv --steps 3 --warmup 1, kernel k_svrg_iter<0, false, 2>',
+    out = ['# rocprofv3 --kernel-trace --pmc <SQ counters> (two passes; tools/prof_round3.sh) -- bench.py --workload tv --steps 30 --warmup 10, kernel k_svrg_outer (T2 = 10 inner iterations per launch)',
            '# mean per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles (guide)']
     for k in sorted(m):
         out.append(f'{k:30s} {m[k]:14.4g}   ({len(vals[k])} launches)')

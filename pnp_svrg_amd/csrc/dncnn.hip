@@ -27,6 +27,7 @@
 //     matrix pipe is the only busy resource by a wide margin.
 #include "common.h"
 #include "wino44.h"
+#include "wino44b.h"
 #include "tilewalk.h"
 #include "reduce.h"
 #include <vector>
@@ -627,6 +628,7 @@ struct pnp_dncnn_plan {
     int n_mid, H, W, batch, num_cu;
     float *w_first, *w_last, *wpack, *upack, *bias;   // device (upack: Winograd F(2,3)-transformed weights)
     float* upack44;                              // Winograd F(4x4,3x3)-transformed weights (dncnn_wino44.hip)
+    uint16_t* upack44b;                          // the same, split into three bf16 terms (dncnn_wino44b.hip; conv mode 6)
     float* b_first;                              // [64] device, zeros unless pnp_dncnn_set_affine
     float b_last, slope;                         // last-layer bias, LeakyReLU slope (0 = ReLU)
     int use_wino;
@@ -684,8 +686,8 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
         // along x, 1 = F(2,3) along x, 0 = direct, 3 = opt-in split-fp16
         const char* ev = getenv("PNP_DNCNN_WINOGRAD");
         p->use_wino = ev ? atoi(ev) : 5;
-        if (p->use_wino != 5 && p->use_wino != 1 && p->use_wino != 0) p->use_wino = 5;      // (unknown value: the default)
-        if (p->use_wino == 5 && !wino44_supports(H, W)) p->use_wino = 1;
+        if (p->use_wino != 6 && p->use_wino != 5 && p->use_wino != 1 && p->use_wino != 0) p->use_wino = 5;      // (unknown value: the default)
+        if (p->use_wino >= 5 && !wino44_supports(H, W)) p->use_wino = 1;
     }
     const size_t act_bytes = (size_t)batch * C * H * W * sizeof(float);
     hipError_t e = hipMalloc(&p->wpack, pack.size() * sizeof(float));
@@ -697,6 +699,12 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
         wino44_pack_weights(w_mid, n_mid, u44.data());
         if (e == hipSuccess) e = hipMalloc(&p->upack44, u44.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(p->upack44, u44.data(), u44.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (wino44b_supports(H, W)) {
+        std::vector<uint16_t> u44b(wino44b_weight_halfwords(n_mid));
+        wino44b_pack_weights(w_mid, n_mid, u44b.data());
+        if (e == hipSuccess) e = hipMalloc(&p->upack44b, u44b.size() * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemcpy(p->upack44b, u44b.data(), u44b.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc(&p->bias, (size_t)n_mid * C * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->bias, b_mid, (size_t)n_mid * C * sizeof(float), hipMemcpyHostToDevice);
@@ -715,7 +723,8 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
     if (e != hipSuccess) {
         set_error(std::string("pnp_dncnn_plan_create: ") + hipGetErrorString(e));
         for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0,
-                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->upack44})
+                        (void*)p->act1, (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->upack44,
+                        (void*)p->upack44b})
             if (q) (void)hipFree(q);
         delete p;
         return PNP_ERR_HIP;
@@ -727,7 +736,7 @@ extern "C" int pnp_dncnn_plan_create(pnp_dncnn_plan** out, int n_mid, const floa
 extern "C" int pnp_dncnn_plan_destroy(pnp_dncnn_plan* p) {
     if (!p) return PNP_OK;
     for (void* q : {(void*)p->wpack, (void*)p->upack, (void*)p->bias, (void*)p->w_first, (void*)p->w_last, (void*)p->act0, (void*)p->act1,
-                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->upack44})
+                    (void*)p->zeros, (void*)p->mm, (void*)p->sse_part, (void*)p->b_first, (void*)p->upack44, (void*)p->upack44b})
         (void)hipFree(q);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -756,7 +765,11 @@ int run_dncnn(pnp_dncnn_plan* p, const T* z_in, bool normalise, double sigma_net
     const bool prof = p->profile && p->ev_used + 2 <= p->ev.size();
     if (prof) PNP_CHECK_HIP(hipEventRecord(p->ev[p->ev_used], s));
     for (int l = 0; l < p->n_mid; ++l) {
-        if (p->use_wino == 5) {
+        if (p->use_wino == 6) {
+            const int rc = wino44b_layer(src, dst, p->upack44b + (size_t)l * wino44b_weight_halfwords(1), p->bias + (size_t)l * C,
+                                         H, W, B, p->num_cu, p->slope, s);
+            if (rc != PNP_OK) return rc;
+        } else if (p->use_wino == 5) {
             const int rc = wino44_layer(src, dst, p->upack44 + (size_t)l * wino44_weight_floats(1), p->bias + (size_t)l * C, p->zeros,
                                         H, W, B, p->num_cu, p->slope, s);
             if (rc != PNP_OK) return rc;
@@ -807,6 +820,9 @@ extern "C" int pnp_dncnn_debug_mid_layer(pnp_dncnn_plan* p, int layer, const flo
     const int H = p->H, W = p->W, B = p->batch, l = layer;
     const int ntiles = B * (H / TR) * (W / TC);
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
+    if (p->use_wino == 6)
+        return wino44b_layer(in, out, p->upack44b + (size_t)l * wino44b_weight_halfwords(1), p->bias + (size_t)l * C, H, W, B, p->num_cu,
+                             p->slope, s);
     if (p->use_wino == 5)
         return wino44_layer(in, out, w44_override ? w44_override : p->upack44 + (size_t)l * wino44_weight_floats(1),
                             p->bias + (size_t)l * C, p->zeros, H, W, B, p->num_cu, p->slope, s, w44_rows);
@@ -831,9 +847,9 @@ extern "C" int pnp_dncnn_set_affine(pnp_dncnn_plan* p, const float* b_first, flo
 
 extern "C" int pnp_dncnn_set_winograd(pnp_dncnn_plan* p, int enable) {
     PNP_CHECK_ARG(p != nullptr, "null plan");
-    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 5,
-                  "mode must be 0 (direct), 1 (Winograd F(2,3) along x) or 5 (Winograd F(4x4,3x3))");
-    PNP_CHECK_ARG(!(enable == 5 && !wino44_supports(p->H, p->W)), "Winograd F(4x4,3x3) needs H % 8 == 0 and W % 64 == 0");
+    PNP_CHECK_ARG(enable == 0 || enable == 1 || enable == 5 || enable == 6,
+                  "mode must be 0 (direct), 1 (Winograd F(2,3) along x), 5 (Winograd F(4x4,3x3)) or 6 (the same on 3 x bf16 splits)");
+    PNP_CHECK_ARG(!(enable >= 5 && !wino44_supports(p->H, p->W)), "Winograd F(4x4,3x3) needs H % 8 == 0 and W % 64 == 0");
     p->use_wino = enable;
     return PNP_OK;
 }
@@ -875,9 +891,10 @@ extern "C" int pnp_dncnn_debug_clock(pnp_dncnn_plan* p, int reps, double* cycles
     const int grid = ntiles < p->num_cu ? ntiles : p->num_cu;
     unsigned long long* d = nullptr;
     PNP_CHECK_HIP(hipMalloc(&d, (size_t)grid * 5 * sizeof(unsigned long long)));
-    if (p->use_wino == 5) {                                     // F(4x4,3x3): 8 x 64 regions, 4 stamps per workgroup
+    if (p->use_wino >= 5) {                                     // F(4x4,3x3): 8 x 64 regions, 4 stamps per workgroup
         const int nt5 = p->batch * (p->H / 8) * (p->W / 64), g5 = nt5 < p->num_cu ? nt5 : p->num_cu;
-        const int rc = wino44_debug_clock(p->act0, p->act1, p->upack44, p->bias, p->H, p->W, p->batch, p->num_cu, reps, d, s);
+        const int rc = p->use_wino == 6 ? wino44b_debug_clock(p->act0, p->act1, p->upack44b, p->bias, p->H, p->W, p->batch, p->num_cu, reps, d, s)
+                                        : wino44_debug_clock(p->act0, p->act1, p->upack44, p->bias, p->H, p->W, p->batch, p->num_cu, reps, d, s);
         if (rc != PNP_OK) { (void)hipFree(d); return rc; }
         std::vector<unsigned long long> h5((size_t)g5 * 4);
         hipError_t e5 = hipMemcpyAsync(h5.data(), d, h5.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);

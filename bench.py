@@ -43,7 +43,9 @@ NET_SIGMA = 15
 # pnp_saga.py:29-31) the direction keeps that bias for ~hist steps, hence the small step size
 SAGA_ETA, SAGA_MB, SAGA_HIST, SAGA_SNR = 5e6, 3000, 50, 20.0
 FLOP_MID_PER_IMAGE = 2 * 9 * 64 * 64 * H * W          # one 64->64 3x3 conv layer, direct form
-WINOGRAD_REDUCTION = {'5': 4.0, '1': 1.5, '0': 1.0}    # F(4x4,3x3) executes 1/4 of the direct form's multiply-adds, F(2,3) along x 2/3
+WINOGRAD_REDUCTION = {'5': 4.0, '1': 1.5, '0': 1.0,   # F(4x4,3x3) executes 1/4 of the direct form's multiply-adds, F(2,3) along x 2/3;
+                      '6': 4.0 / 6.0}                  # the 3 x bf16 split form: 1/4 of the multiply-adds, six bf16 products for each
+BF16_MFMA_PEAK_TFLOPS = 2500.0                        # same guide: dense bf16 peak
 F32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 F32_VALU_PEAK_TFLOPS = 157.3                          # same guide: vector f32 FMA peak (NLM prox)
 HBM_PEAK_GBS = 8000.0
@@ -67,9 +69,10 @@ def parse():
                     help='gloo + PNP_BENCH_ONE_DEVICE=1 rehearses the N>1 path with all ranks on GPU 0')
     ap.add_argument('--graph', action='store_true',
                     help='replay one outer iteration (T2 steps) per hipGraph launch; --steps/--warmup are rounded up to multiples of T2')
-    ap.add_argument('--conv', default=None, choices=['f32-winograd44', 'f32-winograd', 'f32-direct'],
+    ap.add_argument('--conv', default=None, choices=['f32-winograd44', 'f32-winograd', 'f32-direct', 'bf16x3-winograd44'],
                     help='conv kernel of the DnCNN prox (default: f32-winograd44 = F(4x4,3x3), or PNP_DNCNN_WINOGRAD; f32-winograd = F(2,3) along x, '
-                         'f32-direct = implicit GEMM, bit for bit an fmaf chain)')
+                         'f32-direct = implicit GEMM, bit for bit an fmaf chain; bf16x3-winograd44 = opt-in F(4x4,3x3) on the bf16 matrix cores '
+                         'with exact three-way splits: fp32-class accuracy, not the reference\'s arithmetic)')
     ap.add_argument('--host-minibatches', action='store_true', help='pre-draw minibatch index lists on the host')
     ap.add_argument('--no-outer-kernel', action='store_true', help='A/B: config 2 as one launch per inner iteration instead of one per outer iteration')
     ap.add_argument('--no-fold', action='store_true', help='A/B: the outer full-gradient refresh as launches of its own instead of '
@@ -221,14 +224,17 @@ class Workload:
             mode = os.environ.get('PNP_DNCNN_WINOGRAD', '5')
             red = WINOGRAD_REDUCTION.get(mode, 4.0)
             ex = alg / red
+            peak = BF16_MFMA_PEAK_TFLOPS if mode == '6' else F32_MFMA_PEAK_TFLOPS
             return {'bound': 'mfma',
-                    'kernel': {'5': 'pnp::w44::k_mid_wino44 (64->64 3x3 conv, Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32)',
+                    'kernel': {'6': 'pnp::w44b::k_mid_wino44b (64->64 3x3 conv, Winograd F(4x4,3x3) on v_mfma_f32_32x32x16_bf16: every fp32 factor '
+                                    'split exactly into three bf16 terms, six products each; opt-in, fp32-class accuracy)',
+                               '5': 'pnp::w44::k_mid_wino44 (64->64 3x3 conv, Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32)',
                                '1': 'pnp::k_mid_wino (64->64 3x3 conv, Winograd F(2,3) along x on v_mfma_f32_16x16x4_f32)',
                                '0': 'pnp::k_mid (64->64 3x3 conv, direct implicit GEMM on v_mfma_f32_16x16x4_f32)'}.get(mode, mode),
-                    # achieved / frac: what the matrix cores EXECUTE per second against their peak
-                    'achieved': round(ex, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ex / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': _traffic(f'k_mid_B{B}')[0],
-                    'traffic_source': _traffic(f'k_mid_B{B}')[1],
+                    # achieved / frac: what the matrix cores EXECUTE per second against their peak (mode 6: bf16 FLOPs against the bf16 peak)
+                    'achieved': round(ex, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ex / peak, 4), 'traffic': _traffic(f'k_mid_B{B}')[0] if mode != '6' else None,
+                    'traffic_source': _traffic(f'k_mid_B{B}')[1] if mode != '6' else None,
                     'launch_ms': round(ms, 4), 'launches_timed': launches,
                     'flops_per_launch': int(flops / red), 'algorithmic_flops_per_launch': flops,
                     'algorithmic_tflops': round(alg, 2), 'winograd_reduction': red}
@@ -445,7 +451,7 @@ def main():
         print(f'[bench] --gpus {a.gpus} but WORLD_SIZE {world}: using WORLD_SIZE', file=sys.stderr)
 
     if a.conv is not None:
-        os.environ['PNP_DNCNN_WINOGRAD'] = {'f32-winograd44': '5', 'f32-winograd': '1', 'f32-direct': '0'}[a.conv]
+        os.environ['PNP_DNCNN_WINOGRAD'] = {'f32-winograd44': '5', 'f32-winograd': '1', 'f32-direct': '0', 'bf16x3-winograd44': '6'}[a.conv]
     from pnp_svrg_amd import ops
     ops.require_gpu()
 
@@ -524,6 +530,23 @@ def main():
                                                'after_timed_steps_mean': float(np.mean(tr2[-1]))}}
                 del w2
                 torch.cuda.empty_cache()
+            # config 3 once more with the opt-in conv mode 6 (3 x bf16 split F(4x4,3x3); fp32-class accuracy, not the reference's
+            # arithmetic operation for operation -- which is why `value` stays on the exact-fp32 kernel)
+            os.environ['PNP_DNCNN_WINOGRAD'] = '6'
+            try:
+                w6 = Workload('dncnn', 120, rank, a, weights)
+                dt6 = measure(w6, 10, 2, sync_all)
+                tr6 = w6.eng.psnr_trace()
+                secondary['dncnn-bf16x3'] = {'metric': metric_name('dncnn'), 'value': round(120 * 10 / dt6, 2), 'unit': 'inner-iters/s',
+                                             'steps': 10, 'ms_per_step': round(dt6 / 10 * 1e3, 4), 'dtype': 'bf16x3 (three-way exact split of fp32, fp32 accumulation)',
+                                             'config': {'workload': workload_desc('dncnn', wdesc) + ', conv mode 6 (bf16x3-winograd44)', 'batch_per_gpu': 120},
+                                             'roofline': w6.roofline(dt6 / 10),
+                                             'psnr_db': {'initial_mean': float(np.mean(w6.batch.psnr_init())),
+                                                         'after_timed_steps_mean': float(np.mean(tr6[-1]))}}
+                del w6
+            finally:
+                del os.environ['PNP_DNCNN_WINOGRAD']
+            torch.cuda.empty_cache()
             # config 5 on one GPU: the sweep driver with its gather inside the clock (the N > 1 runs are `--workload sweep --gpus N`)
             dt5, warm5, w5, got5 = run_sweep_bench(rank, world, weights, 20, 10, sync_all, None, cdev)
             f5 = sweep_fields(dt5, 20, w5, got5, 1)

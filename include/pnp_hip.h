@@ -235,13 +235,17 @@ int pnp_dncnn_plan_destroy(pnp_dncnn_plan* plan);
  * bias-free ReLU nets: the MMO `simple_CNN` (denoisers/MMODenoise.py:73-101: every conv has a bias, LeakyReLU(0.01),
  * b_mid goes in through plan_create).  b_first: HOST [64] or NULL (= zeros); negative_slope 0 = ReLU.         */
 int pnp_dncnn_set_affine(pnp_dncnn_plan* plan, const float* b_first, float b_last, float negative_slope);
-/* Conv kernel choice for the 64->64 layers (all fp32 on the f32 matrix cores):
+/* Conv kernel choice for the 64->64 layers (0, 1, 5: fp32 on the f32 matrix cores):
  *   5 = Winograd F(4x4,3x3) (default where H % 8 == 0 and W % 64 == 0; executes 1/4 of the direct form's multiply-adds;
  *       accuracy envelope: <= 2e-5 absolute against the reference network on its own weights (measured 8e-7), <= 1e-5
  *       relative against a float64 evaluation on white-noise weights -- about 5x the direct form's rounding error),
  *   1 = Winograd F(2,3) along x (2/3; the default for the other sizes),
- *   0 = direct implicit GEMM (bit-for-bit an fmaf chain; the one-flag way back for parity runs).
- * The default comes from the environment variable PNP_DNCNN_WINOGRAD at plan creation (unset or any other value = 5,
+ *   0 = direct implicit GEMM (bit-for-bit an fmaf chain; the one-flag way back for parity runs),
+ *   6 = opt-in: F(4x4,3x3) on the BF16 matrix cores, every fp32 factor split exactly into three bf16 terms and the six
+ *       products above 2^-24 summed in fp32 -- the same error envelope as 5 (measured: equal to 5's against float64),
+ *       not the reference's arithmetic operation for operation, and at present SLOWER than 5; H % 8 == 0,
+ *       W % 64 == 0.
+ * The default comes from the environment variable PNP_DNCNN_WINOGRAD at plan creation (6 as above; unset or any other value = 5,
  * falling back to 1 where the image size does not allow it).                                                          */
 int pnp_dncnn_set_winograd(pnp_dncnn_plan* plan, int enable);
 /* raw network: r = net(x), x and r [batch][H][W] fp32 (the predicted noise residual)          */

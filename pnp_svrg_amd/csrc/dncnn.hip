@@ -903,9 +903,14 @@ extern "C" int pnp_dncnn_debug_clock(pnp_dncnn_plan* p, int reps, double* cycles
         PNP_CHECK_HIP(e5);
         std::vector<double> c5(g5), r5(g5);
         double wsum = 0, esum = 0;
-        for (int i = 0; i < g5; ++i) { c5[i] = (double)h5[4 * i]; r5[i] = (double)h5[4 * i + 1]; wsum += h5[4 * i + 2]; esum += h5[4 * i + 3]; }
+        double rsum = 0;
+        for (int i = 0; i < g5; ++i) {
+            c5[i] = (double)h5[4 * i]; r5[i] = (double)h5[4 * i + 1]; esum += h5[4 * i + 3];
+            wsum += (double)(h5[4 * i + 2] & 0xFFFFFFFFull); rsum += (double)(h5[4 * i + 2] >> 32);       // (mode 6 packs a second counter above bit 32)
+        }
         if (getenv("PNP_DEBUG_STAMPS"))
-            fprintf(stderr, "[k_mid_wino44 stamps] mean cycles per WG: chunk-end wait + barrier %.0f  epilogue %.0f\n", wsum / g5, esum / g5);
+            fprintf(stderr, "[k_mid_wino44 stamps] mean cycles per WG: chunk-end wait + barrier %.0f  epilogue %.0f  (mode 6: steps 0..5 of the chunks %.0f)\n",
+                    wsum / g5, esum / g5, rsum / g5);
         std::sort(c5.begin(), c5.end());
         std::sort(r5.begin(), r5.end());
         *cycles = c5[g5 / 2];

@@ -18,7 +18,8 @@
 //     and each finishes the pass along y, bias, ReLU and the stores for half of the pair's 32 channels;
 //   * the V image holds bf16 triples: [point][plane][block][8 channels] = 6 bytes per value, 2 x 54 KB, which with the two
 //     24 KB input buffers of the LDS-DMA is 156 KB of the CU's 160 KB.  A thread transforms one (channel, block) patch as
-//     before and writes the three high halves of (v, v - v1, v - v1 - v2) with ds_write_b16_d16_hi.
+//     before; the terms are the high halves of (v, v - v1, v - v1 - v2), paired with the neighbour channel's by v_permlane16_swap
+//     and stored four bytes at a time (put_pair).
 // Everything else (persistent workgroups in the XCD-aware order, LDS-DMA of the halo planes with range-checked padding, the
 // patch transform on the packed-f32 ALU, the chunk pipeline MFMA(k) | transform(k + 1) | DMA(k + 2)) is as in dncnn_wino44.hip.
 #include "common.h"
@@ -109,7 +110,7 @@ struct Ctx {
     Patch P;
     f32x4 b[2][3];                                             // B operands of the current / next point: [parity][(b1|b1), (b2|b2), (b1|b3)]
     const lds_f* dsrc[2];                                      // this lane's patch in the two d buffers
-    lds_c* vdst[2];                                            // its V item (block, channel) in the two V buffers
+    lds_c* vdst[2];                                            // where its 4-byte stores go in the two V buffers (put_pair)
     const lds_c* vsrcA[2];                                     // its B operands: plane b1 of the wave's first point, block lane & 31 ...
     const lds_c* vsrcB[2];                                     //   ... and plane b1 (lower half-wave) / b3 (upper) for the third MFMA
     const __attribute__((address_space(1))) char* ucur;        // weight stream of this wave: scalar cursor (1 KiB per load) ...
@@ -148,9 +149,31 @@ __device__ __forceinline__ void bt6_pk(f32x2 q0, f32x2 q1, f32x2 q2, f32x2 q3, f
     v[4] = t3 - 2.f * sd;
     v[5] = 4.f * q1 + (q5 - 5.f * q3);
 }
-// The exact three-way split of one transformed value and its three 2-byte stores: the high halves of v, r1 = v - hi(v) and
-// r2 = r1 - hi(r1) (both differences are exact; r2 has at most 8 significant bits left).  XI = 6 y + x.
-template <int XI> __device__ __forceinline__ void put_v(lds_c* vdst, float v) {
+// The exact three-way split of a transformed value: the high halves of v, r1 = v - hi(v) and r2 = r1 - hi(r1) (both differences are
+// exact; r2 has at most 8 significant bits left) are the bf16 terms.
+// A lane transforms ONE channel; 2-byte stores of single terms put four lanes on every LDS bank (the loop was bound by the LDS
+// write port).  So two values of the lane, P at point XI and Q at point XI + 18, first go through v_permlane16_swap with the lane
+// 16 further (the same block, the next channel): the even row ends up with both channels of point XI, the odd row with both
+// channels of point XI + 18, and every term is ONE 4-byte store per lane.  `vdst` carries the row's part of the address: the odd
+// row's 18 points further and two dwords rotated inside the 16-byte item -- points 18..35 hold their channels in the order
+// 4..7, 0..3 (wino44b_pack_weights packs the weights of the waves that own those points the same way), which puts the two rows of
+// a store on different banks.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+template <int XI> __device__ __forceinline__ void put_pair(lds_c* vdst, float P, float Q) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(P), __float_as_uint(Q), false, false);
+    const u32x2 u0 = {(unsigned)sw[0], (unsigned)sw[1]};                        // (channel 2 wv, channel 2 wv + 1)
+    const f32x2 v0 = __builtin_bit_cast(f32x2, u0);
+    const f32x2 r1 = v0 - __builtin_bit_cast(f32x2, u0 & 0xFFFF0000u);
+    const u32x2 u1 = __builtin_bit_cast(u32x2, r1);
+    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, u1 & 0xFFFF0000u);
+    const u32x2 u2 = __builtin_bit_cast(u32x2, r2);
+    *(__attribute__((address_space(3))) unsigned*)(vdst + XI * VXI) = __builtin_amdgcn_perm(u0.y, u0.x, 0x07060302u);
+    *(__attribute__((address_space(3))) unsigned*)(vdst + XI * VXI + VPLB) = __builtin_amdgcn_perm(u1.y, u1.x, 0x07060302u);
+    *(__attribute__((address_space(3))) unsigned*)(vdst + XI * VXI + 2 * VPLB) = __builtin_amdgcn_perm(u2.y, u2.x, 0x07060302u);
+}
+// the same split for ONE value and 2-byte stores (the first chunk of a workgroup's first region, outside the pipeline)
+template <int XI> __device__ __forceinline__ void put_v(lds_c* vlo, lds_c* vhi, float v) {
+    lds_c* const vdst = XI < 18 ? vlo : vhi;
     const unsigned u0 = __float_as_uint(v);
     const float r1 = v - __uint_as_float(u0 & 0xFFFF0000u);
     const unsigned u1 = __float_as_uint(r1);
@@ -162,7 +185,7 @@ template <int XI> __device__ __forceinline__ void put_v(lds_c* vdst, float v) {
 }
 // Transform schedule of a chunk over the 18 steps of the MFMA loop: steps 0..5 = row transform of patch row T (and the reads of
 // row T + 1), steps 6 + 4 cp + q (cp = 0..2, q = 0..3) = column pair cp: (0, 5) / (1, 2) / (3, 4); its column transform at
-// q = 0, three of its twelve values split and stored per step
+// q = 0; its twelve values leave as six (y, y + 3) pairs: two pairs in each of the steps q = 0, 1, one in q = 2, 3
 constexpr int col_pair(int t) { return (t - 6) / 4; }
 constexpr int col_q(int t) { return (t - 6) % 4; }
 template <int T> __device__ __forceinline__ void slice_valu(Ctx& c) {
@@ -189,10 +212,15 @@ template <int DPAR, int T> __device__ __forceinline__ void slice_lds(Ctx& c) {
         patch_load<DPAR, T + 1, 1>(c);
     } else if constexpr (T >= 6) {
         constexpr int cp = col_pair(T), q = col_q(T), xa = cp == 0 ? 0 : cp == 1 ? 1 : 3, xb = cp == 0 ? 5 : cp == 1 ? 2 : 4;
-        constexpr int i0 = 3 * q, i1 = 3 * q + 1, i2 = 3 * q + 2;            // value index = 2 y + (0: column xa, 1: column xb)
-        put_v<(i0 >> 1) * 6 + ((i0 & 1) ? xb : xa)>(c.vdst[DPAR], (i0 & 1) ? c.P.v[i0 >> 1].y : c.P.v[i0 >> 1].x);
-        put_v<(i1 >> 1) * 6 + ((i1 & 1) ? xb : xa)>(c.vdst[DPAR], (i1 & 1) ? c.P.v[i1 >> 1].y : c.P.v[i1 >> 1].x);
-        put_v<(i2 >> 1) * 6 + ((i2 & 1) ? xb : xa)>(c.vdst[DPAR], (i2 & 1) ? c.P.v[i2 >> 1].y : c.P.v[i2 >> 1].x);
+        constexpr int u0 = q < 2 ? 2 * q : q + 2, nu = q < 2 ? 2 : 1;         // pair index u = 2 y + (0: column xa, 1: column xb), y = 0..2
+        {
+            constexpr int y = u0 >> 1, x = (u0 & 1) ? xb : xa;
+            put_pair<y * 6 + x>(c.vdst[DPAR], (u0 & 1) ? c.P.v[y].y : c.P.v[y].x, (u0 & 1) ? c.P.v[y + 3].y : c.P.v[y + 3].x);
+        }
+        if constexpr (nu == 2) {
+            constexpr int u1 = u0 + 1, y = u1 >> 1, x = (u1 & 1) ? xb : xa;
+            put_pair<y * 6 + x>(c.vdst[DPAR], (u1 & 1) ? c.P.v[y].y : c.P.v[y].x, (u1 & 1) ? c.P.v[y + 3].y : c.P.v[y + 3].x);
+        }
     }
 }
 // B operand R (0: (b1|b1), 1: (b2|b2), 2: (b1|b3)) of the wave's point T from V buffer VPAR
@@ -230,8 +258,8 @@ template <int K, int T, int VAR, typename DMA> __device__ __forceinline__ void s
     }
     PNP_SLOT();
 }
-template <int K, int VAR, typename DMA, int... T> __device__ __forceinline__ void chunk_steps(Ctx& c, DMA&& dma, std::integer_sequence<int, T...>) {
-    (step<K, T, VAR>(c, dma), ...);
+template <int K, int VAR, int T0, typename DMA, int... T> __device__ __forceinline__ void chunk_steps(Ctx& c, DMA&& dma, std::integer_sequence<int, T...>) {
+    (step<K, T0 + T, VAR>(c, dma), ...);
 }
 // weight loads issued behind the chunk's last DMA piece (step PPW - 1: the piece goes out before that step's two reloads)
 template <int K> constexpr int reloads_behind_dma() {
@@ -240,14 +268,18 @@ template <int K> constexpr int reloads_behind_dma() {
     return n;
 }
 // chunk K of a tile: MFMAs on V buffer K & 1, transform of chunk K + 1, DMA of chunk K + 2
-template <int K, bool STAMP, int VAR, typename DMA> __device__ __forceinline__ void chunk(Ctx& c, DMA&& dma, unsigned long long& t_wait) {
+template <int K, bool STAMP, int VAR, typename DMA> __device__ __forceinline__ void chunk(Ctx& c, DMA&& dma, unsigned long long& t_wait, unsigned long long& t_rows) {
     patch_load<(K + 1) & 1, 0, 0>(c);
     patch_load<(K + 1) & 1, 0, 1>(c);
     b_load<K & 1, 0, 0>(c);
     b_load<K & 1, 0, 1>(c);
     b_load<K & 1, 0, 2>(c);
     PNP_SLOT();
-    chunk_steps<K, VAR>(c, dma, std::make_integer_sequence<int, 18>{});
+    unsigned long long tb = 0;
+    if (STAMP) tb = __builtin_amdgcn_s_memtime();
+    chunk_steps<K, VAR, 0>(c, dma, std::make_integer_sequence<int, 6>{});
+    if (STAMP) t_rows += __builtin_amdgcn_s_memtime() - tb;
+    chunk_steps<K, VAR, 6>(c, dma, std::make_integer_sequence<int, 12>{});
     unsigned long long ta = 0;
     if (STAMP) ta = __builtin_amdgcn_s_memtime();
     // this chunk's DMA pieces have landed: vector-memory operations leave the queue in issue order
@@ -255,27 +287,27 @@ template <int K, bool STAMP, int VAR, typename DMA> __device__ __forceinline__ v
     __syncthreads();
     if (STAMP) t_wait += __builtin_amdgcn_s_memtime() - ta;
 }
-template <bool STAMP, int VAR, typename MK, int... K> __device__ __forceinline__ void all_chunks(Ctx& c, MK&& mk, unsigned long long& t_wait, std::integer_sequence<int, K...>) {
-    (chunk<K, STAMP, VAR>(c, mk(std::integral_constant<int, K>{}), t_wait), ...);
+template <bool STAMP, int VAR, typename MK, int... K> __device__ __forceinline__ void all_chunks(Ctx& c, MK&& mk, unsigned long long& t_wait, unsigned long long& t_rows, std::integer_sequence<int, K...>) {
+    (chunk<K, STAMP, VAR>(c, mk(std::integral_constant<int, K>{}), t_wait, t_rows), ...);
 }
 
 // the first chunk of a workgroup's first tile, outside the pipeline
-template <int X, int Y> __device__ __forceinline__ void put_v_xy(lds_c* vdst, float v) { put_v<Y * 6 + X>(vdst, v); }
-template <int X> __device__ __forceinline__ void transform0_col(const float (&t)[6][6], lds_c* vdst) {
+template <int X> __device__ __forceinline__ void transform0_col(const float (&t)[6][6], lds_c* vlo, lds_c* vhi) {
     float v[6];
     bt6(t[0][X], t[1][X], t[2][X], t[3][X], t[4][X], t[5][X], v);
-    put_v_xy<X, 0>(vdst, v[0]); put_v_xy<X, 1>(vdst, v[1]); put_v_xy<X, 2>(vdst, v[2]);
-    put_v_xy<X, 3>(vdst, v[3]); put_v_xy<X, 4>(vdst, v[4]); put_v_xy<X, 5>(vdst, v[5]);
+    put_v<X>(vlo, vhi, v[0]); put_v<6 + X>(vlo, vhi, v[1]); put_v<12 + X>(vlo, vhi, v[2]);
+    put_v<18 + X>(vlo, vhi, v[3]); put_v<24 + X>(vlo, vhi, v[4]); put_v<30 + X>(vlo, vhi, v[5]);
 }
-__device__ __forceinline__ void transform0(const float* dsrc, lds_c* vdst) {
+// (vlo / vhi: the lane's 2-byte slot in a plane of a point < 18 / >= 18 -- see put_pair for the channel order)
+__device__ __forceinline__ void transform0(const float* dsrc, lds_c* vlo, lds_c* vhi) {
     float t[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const float* row = dsrc + r * PC;                         // LDS column 4 tc of patch row r
         bt6(row[3], row[4], row[5], row[6], row[7], row[8], t[r]);
     }
-    transform0_col<0>(t, vdst); transform0_col<1>(t, vdst); transform0_col<2>(t, vdst);
-    transform0_col<3>(t, vdst); transform0_col<4>(t, vdst); transform0_col<5>(t, vdst);
+    transform0_col<0>(t, vlo, vhi); transform0_col<1>(t, vlo, vhi); transform0_col<2>(t, vlo, vhi);
+    transform0_col<3>(t, vlo, vhi); transform0_col<4>(t, vlo, vhi); transform0_col<5>(t, vlo, vhi);
 }
 
 // ---- epilogue of a region, for the wave's half XH of the transform points (rows y = 3 XH + y') --------------------------------------
@@ -402,7 +434,9 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44b(const float* __restrict_
     const int tc = lane & 15, j = (lane >> 4) & 1, g = lane >> 5;
     const int d_off = 4 * ((2 * wv + j) * (PLANE / 4) + g * PC + tc);               // floats; 16-byte aligned
     const ptrdiff_t hw4 = (ptrdiff_t)4 * H * W, w4 = (ptrdiff_t)4 * W;
-    const int v_off = (g * 16 + tc) * 16 + (2 * wv + j) * 2;                        // bytes: [block][channel] inside a plane
+    // V stores (put_pair): the lane's row of 16 (2 g + j) holds, after the swap, channels 2 wv, 2 wv + 1 of block (g, tc) for a
+    // point < 18 (j = 0) or 18 further (j = 1: two dwords rotated inside the item)
+    const int v_off = (g * 16 + tc) * 16 + ((wv + 2 * j) & 3) * 4 + j * 18 * VXI;
     // MFMA / epilogue role of the lane: block n = lane & 31 (block row n >> 4, column n & 15), half-wave h = lane >> 5
     const int n = lane & 31, h = lane >> 5;
     const unsigned st_off = 4u * (unsigned)((4 * h) * H * W + (4 * (n >> 4)) * W + 4 * (n & 15));
@@ -463,11 +497,12 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44b(const float* __restrict_
         for (int i = 0; i < URING; ++i) c.ur[i] = c.uload_next();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        transform0((const float*)lds + d_off, (lds_c*)(ldsp + D_BYTES + v_off));
+        lds_c* const v0 = ldsp + D_BYTES + (g * 16 + tc) * 16;
+        transform0((const float*)lds + d_off, v0 + (2 * wv + j) * 2, v0 + ((2 * wv + j + 4) & 7) * 2);
         __syncthreads();
     }
 
-    unsigned long long t0 = 0, r0 = 0, t_epi = 0, t_wait = 0;
+    unsigned long long t0 = 0, r0 = 0, t_epi = 0, t_wait = 0, t_rows = 0;
     if (STAMP) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (; tile < limit; tile += tw_.step) {
         asm volatile("" : "+v"(c.ulane));                                        // the weight loads stay inside the tile loop
@@ -481,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44b(const float* __restrict_
             const TileDma& td = K + 2 < NCH ? cur : nxt;
             const i32x4 rs = chunk_rsrc(td, (K + 2) % NCH);
             return [&, rs](int piece) { dma_piece(td, rs, K & 1, piece); };
-        }, t_wait, std::make_integer_sequence<int, NCH>{});
+        }, t_wait, t_rows, std::make_integer_sequence<int, NCH>{});
 
         unsigned long long te = 0;
         if (STAMP) te = __builtin_amdgcn_s_memtime();
@@ -514,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void k_mid_wino44b(const float* __restrict_
     if (STAMP && tid == 0) {
         stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
         stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
-        stamps[4 * blockIdx.x + 2] = t_wait;
+        stamps[4 * blockIdx.x + 2] = t_wait + (t_rows << 32);          // (two counters in one word: steps 0..5 of the chunks above bit 32)
         stamps[4 * blockIdx.x + 3] = t_epi;
     }
 }
@@ -526,7 +561,7 @@ bool wino44b_supports(int H, int W) { return H % 8 == 0 && W % w44b::TC == 0; }
 size_t wino44b_weight_halfwords(int n_mid) { return (size_t)n_mid * 4 * w44b::NLOADS * 64 * 8; }
 
 // w_mid [n_mid][64][64][3][3] (BN folded) -> upack[l][wave][chunk k][point t][operand ab][lane][8 channels] (bf16 bit patterns):
-// wave = 2 xh + ch, point xi = 18 xh + t, cout = 32 ch + (lane & 31), cin = 8 k + e; operand 0 = (a1 | a2), 1 = (a3 | a1) by
+// wave = 2 xh + ch, point xi = 18 xh + t, cout = 32 ch + (lane & 31), cin = 8 k + ((e + 4 xh) & 7); operand 0 = (a1 | a2), 1 = (a3 | a1) by
 // half-wave (lane >> 5), with U = G g G^T evaluated in float64, rounded to fp32 (the fp32 kernel's value) and split by truncation
 void wino44b_pack_weights(const float* w_mid, int n_mid, uint16_t* out) {
     static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -550,11 +585,12 @@ void wino44b_pack_weights(const float* w_mid, int n_mid, uint16_t* out) {
                         const float r2 = r1 - flt(u2);
                         const uint16_t a1 = (uint16_t)(u1 >> 16), a2 = (uint16_t)(u2 >> 16), a3 = (uint16_t)(bits(r2) >> 16);
                         const int xi = 6 * xy + xx, xh = xi / 18, t = xi % 18, wave = 2 * xh + ch;
+                        const int es = (e + 4 * xh) & 7;                          // points 18..35 keep their channels in the order 4..7, 0..3 (put_pair)
                         const size_t base = ((((size_t)(l * 4 + wave) * w44b::NCH + k) * 18 + t) * 2) * 512;
-                        out[base + (size_t)r * 8 + e] = a1;                       // operand 0, lower half-wave
-                        out[base + (size_t)(32 + r) * 8 + e] = a2;                // operand 0, upper half-wave
-                        out[base + 512 + (size_t)r * 8 + e] = a3;                 // operand 1, lower
-                        out[base + 512 + (size_t)(32 + r) * 8 + e] = a1;          // operand 1, upper
+                        out[base + (size_t)r * 8 + es] = a1;                      // operand 0, lower half-wave
+                        out[base + (size_t)(32 + r) * 8 + es] = a2;               // operand 0, upper half-wave
+                        out[base + 512 + (size_t)r * 8 + es] = a3;                // operand 1, lower
+                        out[base + 512 + (size_t)(32 + r) * 8 + es] = a1;         // operand 1, upper
                     }
             }
 }

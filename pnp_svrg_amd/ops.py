@@ -175,7 +175,8 @@ class DncnnPlan:
     def __init__(self, weights, H, W, batch, winograd=None):
         """winograd: 5 = Winograd F(4x4,3x3) conv kernel (default where H % 8 == 0 and W % 64 == 0; fp32, a quarter of the
         matrix-core work), True / 1 = F(2,3) along x (two thirds; the default elsewhere), False / 0 = direct implicit GEMM
-        (bit-for-bit an fmaf chain), None = env PNP_DNCNN_WINOGRAD or the default."""
+        (bit-for-bit an fmaf chain), 6 = opt-in F(4x4,3x3) on the bf16 matrix cores with three-way exact splits (fp32-class accuracy,
+        currently slower than 5), None = env PNP_DNCNN_WINOGRAD or the default."""
         import numpy as np
         require_gpu()
         n = int(weights['n_layers'])

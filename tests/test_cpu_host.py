@@ -299,6 +299,17 @@ def test_w44_accumulators_untouched():
     assert '0 problem(s)' in out.stdout
 
 
+def test_w44b_accumulators_untouched():
+    """The same for the 3 x bf16 split kernel (csrc/dncnn_wino44b.hip, conv mode 6): 18 accumulator tuples of 16 registers, 24 MFMAs
+    each, untouched between a tuple's first MFMA of a region and the epilogue's wait states (tools/check_w44b_isa.py)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_w44b_isa.py')], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert '2 kernel instantiation(s) checked, 0 problem(s)' in out.stdout
+
+
 def test_fused_loads_untouched():
     """The global loads of the one-kernel iteration (csrc/csmri_fused.hip) are hand-issued inline asm with hand-counted
     `s_waitcnt vmcnt(N)` in front of their uses: hipcc does not know that their results arrive later and could read, overwrite

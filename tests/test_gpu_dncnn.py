@@ -158,7 +158,7 @@ def test_simplecnn_family(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('winograd', [True, False, 5])
+@pytest.mark.parametrize('winograd', [True, False, 5, 6])
 def test_mmo_denoiser_vs_reference(winograd):
     """SURVEY 8(f) n3: MMODenoiser (20-layer bias / LeakyReLU(0.01) / skip net, transposed input, both clamps;
     reference denoisers/MMODenoise.py:18-40,73-128) through the MFMA conv stack vs the reference's own classes
@@ -172,7 +172,7 @@ def test_mmo_denoiser_vs_reference(winograd):
         sd['module.' + n + '.weight'] = torch.from_numpy(g[f'conv{i}.weight'])
         sd['module.' + n + '.bias'] = torch.from_numpy(g[f'conv{i}.bias'])
     old = os.environ.get('PNP_DNCNN_WINOGRAD')
-    os.environ['PNP_DNCNN_WINOGRAD'] = str(int(winograd))     # 5 / 1 = Winograd kernels (LeakyReLU builds), 0 = direct
+    os.environ['PNP_DNCNN_WINOGRAD'] = str(int(winograd))     # 6 / 5 / 1 = Winograd kernels (LeakyReLU builds), 0 = direct
     try:
         den = MMODenoiser(model=sd, channels=1)
         for name in ('sq', 'rect'):
@@ -281,3 +281,80 @@ def test_wino44_guard_bands():
         assert torch.equal(xin[GUARD:GUARD + n], torch.from_numpy(x).cuda()) and torch.equal(vw, wk)
         assert torch.isfinite(vout).all()
         assert (vout - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (H, Wd, B, rows)
+
+
+def test_bf16x3_conv_mode(W15, io):
+    """Conv mode 6 (`k_mid_wino44b`: F(4x4,3x3) on the bf16 matrix cores, every fp32 factor split exactly into three bf16 terms, six
+    products) is fp32-class: (a) the reference network's own output within the bound of the fp32 kernels; (b) against float64 at
+    three activation scales no worse than the fp32 F(4x4,3x3) kernel (bf16 keeps fp32's exponent range: nothing depends on the
+    scale); (c) shapes whose regions all touch an edge, region counts that do not divide the grid, images of a batch equal to
+    their single-image results; (d) run-to-run identical; (e) NaN guard bands around input and output intact."""
+    import torch.nn.functional as F
+    from pnp_svrg_amd import ops
+    from pnp_svrg_amd.denoisers import random_dncnn_weights
+    x = dev(io['net256_in'][None])
+    r6 = ops.DncnnPlan(W15, 256, 256, 1, winograd=6).forward(x).cpu().numpy()[0]
+    r5 = ops.DncnnPlan(W15, 256, 256, 1, winograd=5).forward(x).cpu().numpy()[0]
+    assert not np.array_equal(r6, r5)                                       # really another kernel
+    assert np.abs(r6 - io['net256_out']).max() <= 2e-5 and np.abs(r6 - r5).max() <= 1e-5
+    print('max |bf16x3 F(4x4,3x3) - reference net| %.2e   (fp32 F(4x4,3x3): %.2e)' % (
+        np.abs(r6 - io['net256_out']).max(), np.abs(r5 - io['net256_out']).max()))
+    # (b)
+    for scale in (1.0, 1e-3, 50.0):
+        rng = np.random.default_rng(11)
+        n = 64
+        w = {'n_layers': np.int64(3),
+             'conv0.weight': (rng.standard_normal((64, 1, 3, 3)) * scale).astype(np.float32),
+             'conv1.weight': (rng.standard_normal((64, 64, 3, 3)) / 24.0).astype(np.float32),
+             'conv1.bias': (rng.standard_normal(64) * 0.1 * scale).astype(np.float32),
+             'conv2.weight': (rng.standard_normal((1, 64, 3, 3)) / 24.0).astype(np.float32)}
+        xs = rng.random((2, n, n)).astype(np.float32)
+        t = torch.from_numpy(xs).double()[:, None]
+        t = F.relu(F.conv2d(t, torch.from_numpy(w['conv0.weight']).double(), padding=1))
+        t = F.relu(F.conv2d(t, torch.from_numpy(w['conv1.weight']).double(), torch.from_numpy(w['conv1.bias']).double(), padding=1))
+        ref = F.conv2d(t, torch.from_numpy(w['conv2.weight']).double(), padding=1)[:, 0].numpy()
+        err = {m: np.abs(ops.DncnnPlan(w, n, n, 2, winograd=m).forward(dev(xs)).cpu().numpy().astype(np.float64) - ref).max() / np.abs(ref).max()
+               for m in (5, 6)}
+        print(f'scale {scale}: relative max error vs float64 -- fp32 F(4x4,3x3) {err[5]:.2e}, bf16x3 F(4x4,3x3) {err[6]:.2e}')
+        assert err[6] < 1e-5 and err[6] <= 1.25 * err[5]
+    # (c)
+    w = random_dncnn_weights(5, seed=3)
+    rng = np.random.default_rng(8)
+    for (H, Wd, B) in ((8, 64, 1), (72, 128, 3), (128, 64, 5), (64, 192, 2)):
+        xs = rng.random((B, H, Wd)).astype(np.float32) + 3.0
+        r0 = ops.DncnnPlan(w, H, Wd, B, winograd=0).forward(dev(xs)).cpu().numpy()
+        rb = ops.DncnnPlan(w, H, Wd, B, winograd=6).forward(dev(xs)).cpu().numpy()
+        assert np.abs(rb - r0).max() <= 2e-5 * max(1.0, np.abs(r0).max()), (H, Wd, B, np.abs(rb - r0).max())
+    with pytest.raises(Exception):
+        ops.DncnnPlan(w, 40, 96, 1, winograd=6)
+    for B in (6, 5):
+        xb = rng.random((B, 256, 256)).astype(np.float32)
+        rb = ops.DncnnPlan(W15, 256, 256, B, winograd=6).forward(dev(xb)).cpu().numpy()
+        one = ops.DncnnPlan(W15, 256, 256, 1, winograd=6).forward(dev(xb[1:2])).cpu().numpy()[0]
+        assert np.array_equal(rb[1], one), B
+    # (d)
+    plan = ops.DncnnPlan(W15, 256, 256, 7, winograd=6)
+    xr = torch.rand(7, 256, 256, device='cuda')
+    first = plan.forward(xr).clone()
+    for _ in range(5):
+        assert torch.equal(plan.forward(xr), first)
+    # (e)
+    w4 = random_dncnn_weights(4, seed=9)
+    GUARD = 1 << 18
+    for (H, Wd, B) in ((72, 128, 3), (256, 256, 5), (8, 64, 1)):
+        n = B * 64 * H * Wd
+        plan6, plan0 = ops.DncnnPlan(w4, H, Wd, B, winograd=6), ops.DncnnPlan(w4, H, Wd, B, winograd=0)
+        xs = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+        xin = torch.full((n + 2 * GUARD,), float('nan'), dtype=torch.float32, device='cuda')
+        yout = torch.full((n + 2 * GUARD,), float('nan'), dtype=torch.float32, device='cuda')
+        xin[GUARD:GUARD + n] = xs
+        yout[GUARD:GUARD + n] = 0.0
+        vin, vout = xin[GUARD:GUARD + n].view(B, 64, H, Wd), yout[GUARD:GUARD + n].view(B, 64, H, Wd)
+        plan6.debug_mid_layer(1, vin, vout)
+        ref = torch.empty((B, 64, H, Wd), dtype=torch.float32, device='cuda')
+        plan0.debug_mid_layer(1, xs.view(B, 64, H, Wd), ref)
+        torch.cuda.synchronize()
+        for t in (xin, yout):
+            assert torch.isnan(t[:GUARD]).all() and torch.isnan(t[GUARD + n:]).all(), (H, Wd, B)
+        assert torch.equal(xin[GUARD:GUARD + n], xs) and torch.isfinite(vout).all()
+        assert (vout - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (H, Wd, B)

@@ -278,6 +278,31 @@ def test_config3_full_size_vs_oracle(api, g_csmri):
         assert np.abs(r['z'] - ro['z']).max() < 5e-4
 
 
+def test_config3_bf16x3_conv_vs_oracle(api, g_csmri, monkeypatch):
+    """The config-3 loop of test_config3_full_size_vs_oracle with the opt-in conv mode 6 (F(4x4,3x3) on three-way bf16 splits):
+    every logged PSNR within +-0.01 dB of the oracle loop (torch-CPU fp32 net) on identical seeds."""
+    from conftest import golden
+    from oracle import denoise as od, problems as op
+    A, P, D = api
+    monkeypatch.setenv('PNP_DNCNN_WINOGRAD', '6')
+    wts = dict(golden('dncnn_noise15.npz'))
+    img = g_csmri['r256_img']
+    np.random.seed(0)
+    p = P.CSMRI(None, H=256, W=256, sample_prob=0.2, snr=20., img=img, dtype=torch.float32)
+    np.random.seed(1)
+    r = A.pnp_svrg(p, D.RealSN_DnCNNDenoiser('DnCNN', 15, weights=wts), 2e3, 2 + 2 * (3 + 5 * 5), 5, 1000,
+                   verbose=False, converge_check=False, clock=ol.CountingClock(), variant='svrg')
+    np.random.seed(0)
+    po = op.CSMRI(None, H=256, W=256, sample_prob=0.2, snr=20., img=img)
+    np.random.seed(1)
+    ro = ol.pnp_svrg(po, od.DnCNNDenoiser(wts, 15), 2e3, 2 + 2 * (3 + 5 * 5), 5, 1000, converge_check=False,
+                     clock=ol.CountingClock(), variant='svrg')
+    ps, pso = np.array(r['psnr_per_iter']), np.array(ro['psnr_per_iter'])
+    assert len(ps) == len(pso) == 13
+    assert np.abs(ps - pso).max() <= 0.01 + 1e-9, (ps, pso)
+    assert np.abs(r['z'] - ro['z']).max() < 5e-4
+
+
 def test_svrg_graph_replay_equals_eager_loop(api):
     """pnp_svrg with a deterministic clock replays whole outer iterations as hipGraphs (graph=None): identical result
     dict to the eager loop (graph=False) -- iterate, PSNR log, time bookkeeping, RNG stream position, denoiser call

@@ -246,7 +246,12 @@ template <int K, int T, int VAR, typename DMA> __device__ __forceinline__ void s
     mfma<in_agpr(T)>(c.acc[T], ua, b1);
     PNP_SLOT();
     if constexpr (T + 1 < 18 && VAR != 13 && VAR != 15) b_load<VPAR, T + 1, 1>(c);
-    if constexpr (T < PPW && VAR != 11 && VAR != 15) dma(T);
+    if constexpr (T == 0 && VAR != 11 && VAR != 15) {
+        // all of the chunk's DMA pieces at once, in front of every weight load the chunk issues: a weight load cannot retire before
+        // the pieces ahead of it in the wave's queue have come back, so what counts is when the LAST piece goes out
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma(i);
+    }
     if constexpr (VAR != 15 && !(VAR == 14 && T >= 6) && !(VAR == 16 && T < 5)) slice_lds<DPAR, T>(c);
     PNP_SLOT();
     mfma<in_agpr(T)>(c.acc[T], ub, b2);
@@ -261,10 +266,10 @@ template <int K, int T, int VAR, typename DMA> __device__ __forceinline__ void s
 template <int K, int VAR, int T0, typename DMA, int... T> __device__ __forceinline__ void chunk_steps(Ctx& c, DMA&& dma, std::integer_sequence<int, T...>) {
     (step<K, T0 + T, VAR>(c, dma), ...);
 }
-// weight loads issued behind the chunk's last DMA piece (step PPW - 1: the piece goes out before that step's two reloads)
+// weight loads issued behind the chunk's DMA pieces (step 0: the pieces go out before that step's two reloads)
 template <int K> constexpr int reloads_behind_dma() {
     int n = 0;
-    for (int p = PPW - 1; p < 18; ++p) n += (2 * (K * 18 + p) + URING + 1 < NLOADS) ? 2 : 0;
+    for (int p = 0; p < 18; ++p) n += (2 * (K * 18 + p) + URING + 1 < NLOADS) ? 2 : 0;
     return n;
 }
 // chunk K of a tile: MFMAs on V buffer K & 1, transform of chunk K + 1, DMA of chunk K + 2

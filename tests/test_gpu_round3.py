@@ -127,6 +127,93 @@ def test_dncnn_prox_full_length_vs_oracle(g_csmri):
         assert np.abs(eng.z.double().cpu().numpy().ravel() - ro['z']).max() <= 1e-3
 
 
+def test_timed_path_device_draws_vs_oracle():
+    """What `bench.py --workload tv` times -- device-drawn minibatches (`k_draw_thr` -> bit-packed selectors) and ONE kernel per
+    outer iteration (`k_svrg_outer`) at a batch that takes the one-kernel path (B = 192) -- against the oracle loop fed the
+    very minibatches the device drew (decoded from the selector bits): +-0.01 dB on every logged PSNR and |z - z_oracle| <= 1e-3,
+    for items that share a problem (each item draws its own minibatches) and for three different sampling ratios."""
+    import problems as P
+    from oracle import denoise as od, problems as op
+    from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, TVProx
+    n_outer, B = 3, 192
+    ratios = (0.2, 0.3, 0.5)
+    probs = []
+    for k, a in enumerate(ratios):
+        np.random.seed(10 + k)
+        probs.append(P.CSMRI(IMG256, H=256, W=256, sample_prob=a, snr=20., upload=False))
+    batch = CsmriBatch.from_problems([probs[i % 3] for i in range(B)])
+    eng = SvrgEngine(batch, TVProx(), ETA, T2, MB, variant='svrg', seed=5)
+    assert eng.fused and eng.outer_kernel_ok()
+    sel = []
+    for _ in range(n_outer):
+        eng.run_outer(1)                                        # one draw launch + one k_svrg_outer launch
+        sel.append(eng.mbs.selbits.cpu().numpy().copy())        # [T2][B][kx][ky >> 5] words of this outer iteration
+    tr = eng.psnr_trace()
+    assert tr.shape == (n_outer * T2, B)
+    z = eng.z.double().cpu().numpy().reshape(B, -1)
+    shifts = np.arange(32, dtype=np.uint32)
+    seen = []
+    for item in (0, 3, 1, 2, 191):
+        k = item % 3
+        mbs = []
+        for o in range(n_outer):
+            for j in range(T2):
+                w = sel[o][j][item].view(np.uint32)                                  # [256 kx][8]
+                ind = ((w[:, :, None] >> shifts) & 1).reshape(256, 256).T.astype(int)  # [ky][kx] = the H x W indicator select_mb returns
+                assert ind.sum() == MB and (ind <= probs[k].mask).all()
+                mbs.append(ind)
+        seen.append(np.stack(mbs[:2]))
+        np.random.seed(10 + k)
+        po = op.CSMRI(IMG256, H=256, W=256, sample_prob=ratios[k], snr=20.)
+        assert np.array_equal(po.mask, probs[k].mask)
+        it = iter(mbs)
+        po.select_mb = lambda size: next(it)
+        ro = ol.pnp_svrg(po, od.TVDenoiser(), ETA, 2 + n_outer * 53 - 1, T2, MB, converge_check=False, clock=ol.CountingClock(), variant='svrg')
+        ref = _engine_rows(ro['psnr_per_iter'], n_outer)
+        assert np.abs(tr[:, item] - ref).max() <= PSNR_TOL, (item, np.abs(tr[:, item] - ref).max())
+        assert np.abs(z[item] - ro['z']).max() <= 1e-3, item
+    assert not np.array_equal(seen[0], seen[1])                 # items 0 and 3 share a problem, not their minibatches
+
+
+def test_timed_path_dncnn_device_draws_vs_oracle(g_csmri):
+    """The same for what the default `bench.py` line times (config 3): device-drawn minibatches, the streaming CSMRI kernels a
+    batch below 192 takes, the DnCNN prox with the default F(4x4,3x3) conv kernel -- two outer iterations of a small batch
+    against the oracle loop (torch-CPU fp32 net) fed the decoded device draws: +-0.01 dB, |z - z_oracle| <= 1e-3."""
+    import problems as P
+    from oracle import denoise as od, problems as op
+    from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, DnCNNProx
+    wts = dict(golden('dncnn_noise15.npz'))
+    img = g_csmri['r256_img']
+    n_outer, B = 2, 4
+    np.random.seed(21)
+    ph = P.CSMRI(None, H=256, W=256, sample_prob=0.2, snr=20., img=img, upload=False)
+    batch = CsmriBatch.from_problems([ph] * B)
+    eng = SvrgEngine(batch, DnCNNProx(wts, 15), ETA, T2, MB, variant='svrg', seed=11)
+    assert not eng.fused
+    sel = []
+    for _ in range(n_outer):
+        for _ in range(T2):
+            eng.step()                                          # device draws: T2 selections per outer iteration
+        sel.append(eng.mbs.selbits.cpu().numpy().copy())
+    tr = eng.psnr_trace()
+    z = eng.z.double().cpu().numpy().reshape(B, -1)
+    shifts = np.arange(32, dtype=np.uint32)
+    for item in (0, 3):
+        mbs = [((sel[o][j][item].view(np.uint32)[:, :, None] >> shifts) & 1).reshape(256, 256).T.astype(int)
+               for o in range(n_outer) for j in range(T2)]
+        assert all(m.sum() == MB for m in mbs)
+        np.random.seed(21)
+        po = op.CSMRI(None, H=256, W=256, sample_prob=0.2, snr=20., img=img)
+        it = iter(mbs)
+        po.select_mb = lambda size: next(it)
+        ro = ol.pnp_svrg(po, od.DnCNNDenoiser(wts, 15), ETA, 2 + n_outer * 53 - 1, T2, MB, converge_check=False, clock=ol.CountingClock(),
+                         variant='svrg')
+        ref = _engine_rows(ro['psnr_per_iter'], n_outer)
+        assert np.abs(tr[:, item] - ref).max() <= PSNR_TOL, (item, np.abs(tr[:, item] - ref).max())
+        assert np.abs(z[item] - ro['z']).max() <= 1e-3, item
+    assert not np.array_equal(tr[:, 0], tr[:, 3]) or not np.array_equal(z[0], z[3])      # different draws, different paths
+
+
 # ------------------------------------------------------------------------------------------------ general sweep runner
 def _smooth_images(n, count, seed):
     rng = np.random.default_rng(seed)

@@ -226,6 +226,54 @@ def _smooth_images(n, count, seed):
 
 
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_timed_path_saga_nlm_device_draws_vs_oracle(dtype):
+    """Config 4's timed path (`bench.py --workload saga-nlm`): SagaEngine over a DeblurBatch with DEVICE-drawn minibatches
+    (threshold descriptors read by the gradient kernel) and the NLM prox, against `oracle.loops.pnp_saga` fed the same selections
+    (the draw is a function of (seed, step, problem): materialised here with `indicator_from_thresholds`) and the same replaced
+    table rows: f64 identical, f32 +-0.01 dB."""
+    import problems as P
+    from pnp_svrg_amd import ops
+    from pnp_svrg_amd.engine import DeblurBatch, NLMProx, make_engine
+    from oracle import denoise as od, problems as op
+    n, mb, hist, n_it, eta, seed = 64, 300, 4, 6, 1e7, 5
+    imgs = _smooth_images(n, 2, 3)
+    spec = [(0, 0, 20.0), (5, 1, 20.0), (2, 0, 10.0)]                     # (constructor seed, image, snr)
+    probs = []
+    for sd, im, snr in spec:
+        np.random.seed(sd)
+        probs.append(P.Deblur(None, H=n, W=n, kernel='Minimal', scale_percent=100, snr=snr, img=imgs[im], dtype=dtype, upload=False))
+    batch = DeblurBatch.from_problems(probs, dtype=dtype)
+    B = batch.B
+    eng = make_engine(batch, NLMProx(), eta, 1, mb, algorithm='saga', hist_size=hist, seed=seed)
+    rs = np.random.RandomState(1)                                         # the legacy stream the oracle loop draws its rows from
+    rows = [int(rs.choice(hist, 1).item()) for _ in range(n_it)]
+    for k in range(n_it):
+        eng.step(r=rows[k])                                               # device draws; the replaced row imposed
+    tr = eng.psnr_trace()
+    z = eng.z.double().cpu().numpy().reshape(B, -1)
+    # the selections the device used: the table-filling draw (step id 0xFFFFFFFF), then steps 0 .. n_it - 1
+    steps = [0xFFFFFFFF] + list(range(n_it))
+    ind = [ops.indicator_from_thresholds(batch.M, ops.draw_thresholds(batch.M, B, mb, seed, st, 1)[0]).cpu().numpy() for st in steps]
+    for b, (sd, im, snr) in enumerate(spec):
+        np.random.seed(sd)
+        po = op.Deblur(None, H=n, W=n, kernel='Minimal', scale_percent=100, snr=snr, img=imgs[im])
+        mbs = [np.asarray(i[b]).reshape(-1).astype(int) for i in ind]
+        assert all(m.sum() == mb for m in mbs)
+        it = iter(mbs)
+        po.select_mb = lambda size: next(it)
+        d = od.NLMDenoiser()
+        d.sigma = 1.0
+        np.random.seed(1)
+        ro = ol.pnp_saga(po, d, eta, 5 * n_it - 1, mb, hist_size=hist, converge_check=False, clock=ol.CountingClock())
+        ref = np.array(ro['psnr_per_iter'])
+        assert len(ref) == n_it + 1
+        if dtype == torch.float64:
+            assert np.array_equal(tr[:, b], ref[1:]) and np.abs(z[b] - ro['z']).max() <= 1e-9
+        else:
+            assert np.abs(tr[:, b] - ref[1:]).max() <= PSNR_TOL and np.abs(z[b] - ro['z']).max() <= 1e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
 def test_sweep_runner_deblur_nlm_saga_vs_oracle(dtype):
     """One cell of the reference's sweep beyond CSMRI (script_diff_sampratio_set12.py:23-25: DeblurSR x NLM x pnp_saga): three
     legacy-seeded items in ONE batch through `sweep.make_runner`, each against `oracle.loops.pnp_saga` on the same seeds

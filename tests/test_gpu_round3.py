@@ -225,6 +225,54 @@ def _smooth_images(n, count, seed):
     return out
 
 
+@pytest.mark.parametrize('algo', ['sgd', 'sarah'])
+def test_per_step_engines_device_draws_vs_oracle(algo):
+    """SgdEngine / SarahEngine on DEVICE-drawn minibatches (a window of steps per draw launch) against the oracle loops fed the
+    same selections -- the draw is a function of (seed, step, problem), re-drawn here step by step as bit-packed selectors and
+    decoded -- in float64: identical PSNR logs, |z - z_oracle| <= 1e-9.  Three sampling ratios in one batch."""
+    import problems as P
+    from oracle import denoise as od, problems as op
+    from pnp_svrg_amd.engine import CsmriBatch, TVProx, make_engine
+    img64 = os.path.join(GOLDEN, 'synth64.png')
+    n, mb, T2_, eta, seed, decay = 64, 150, 4, 5e2, 3, 0.9
+    steps = 2 * T2_ + 1 if algo == 'sarah' else 20             # (sgd: more steps than one draw window holds)
+    ratios = (0.3, 0.5, 0.8)
+    probs = []
+    for k, a in enumerate(ratios):
+        np.random.seed(30 + k)
+        probs.append(P.CSMRI(img64, H=n, W=n, sample_prob=a, snr=20., dtype=torch.float64, upload=False))
+    batch = CsmriBatch.from_problems(probs, dtype=torch.float64)
+    eng = make_engine(batch, TVProx(), eta, T2_, mb, algorithm=algo, seed=seed, lr_decay=decay)
+    for _ in range(steps):
+        eng.step()
+    tr = eng.psnr_trace()
+    z = eng.z.cpu().numpy().reshape(batch.B, -1)
+    shifts = np.arange(32, dtype=np.uint32)
+    sb = torch.zeros((1, batch.B, n, n // 32), dtype=torch.int32, device='cuda')
+    sel = []
+    for st in range(steps):
+        batch.plan.draw_thresholds(batch.bits, mb, seed, st, 1, selbits=sb)
+        sel.append(sb.cpu().numpy().copy()[0])
+    for b, a in enumerate(ratios):
+        mbs = [((sel[st][b].view(np.uint32)[:, :, None] >> shifts) & 1).reshape(n, n).T.astype(int) for st in range(steps)]
+        assert all(m.sum() == mb and (m <= probs[b].mask).all() for m in mbs)
+        np.random.seed(30 + b)
+        po = op.CSMRI(img64, H=n, W=n, sample_prob=a, snr=20.)
+        it = iter(mbs)
+        po.select_mb = lambda size: next(it)
+        kw = dict(converge_check=False, clock=ol.CountingClock(), lr_decay=decay)
+        if algo == 'sgd':
+            ro = ol.pnp_sgd(po, od.TVDenoiser(), eta, 5 * steps - 2, mb, **kw)
+            ref = np.array(ro['psnr_per_iter'])[1:]
+        else:
+            o, j = (steps - 1) // T2_, (steps - 1) % T2_
+            ro = ol.pnp_sarah(po, od.TVDenoiser(), eta, 1 + o * (5 + 5 * T2_) + 5 + 5 * j + 1, T2_, mb, **kw)
+            ref = np.array(ro['psnr_per_iter'])                  # outer prox entries included, like the engine's log
+        assert len(ref) == tr.shape[0], (len(ref), tr.shape)
+        assert np.abs(tr[:, b] - ref).max() <= 1e-9, (algo, b)
+        assert np.abs(z[b] - ro['z']).max() <= 1e-9
+
+
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
 def test_timed_path_saga_nlm_device_draws_vs_oracle(dtype):
     """Config 4's timed path (`bench.py --workload saga-nlm`): SagaEngine over a DeblurBatch with DEVICE-drawn minibatches

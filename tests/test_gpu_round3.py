@@ -225,6 +225,32 @@ def _smooth_images(n, count, seed):
     return out
 
 
+def test_full_size_batches_items_do_not_depend_on_the_batch():
+    """The benchmarked batch sizes themselves (config 2: B = 1024 through `k_svrg_outer`; config 3: B = 120 through the streaming
+    kernels + DnCNN): a reconstruction never sees its neighbours, and device draws are keyed by (seed, step, problem), so the first
+    items of the full-size batch must equal, BIT FOR BIT, the same items run in a small batch -- iterate and PSNR log."""
+    from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, TVProx, DnCNNProx
+    wts = dict(golden('dncnn_noise15.npz'))
+    for (B_full, B_small, mk_prox, n_outer) in ((1024, 192, lambda: TVProx(), 2), (120, 8, lambda: DnCNNProx(wts, 15), 1)):
+        big = CsmriBatch.synthetic(B_full, 256, 256, 0.2, 20.0, seed=100)
+        small = CsmriBatch.synthetic(B_small, 256, 256, 0.2, 20.0, seed=100)      # (one Generator stream, problem after problem: the same first problems)
+        assert torch.equal(small.xrec, big.xrec[:B_small]) and torch.equal(small.bits, big.bits[:B_small])
+        out = []
+        for batch in (big, small):
+            eng = SvrgEngine(batch, mk_prox(), ETA, T2, MB, variant='svrg', seed=1)
+            if eng.outer_kernel_ok():
+                eng.run_outer(n_outer)
+            else:
+                for _ in range(n_outer * T2):
+                    eng.step()
+            out.append((eng.z[:B_small].clone(), eng.psnr_trace()[:, :B_small].copy()))
+            del eng
+        assert torch.equal(out[0][0], out[1][0]), B_full
+        assert np.array_equal(out[0][1], out[1][1]), B_full
+        del big, small, out
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('algo', ['sgd', 'sarah'])
 def test_per_step_engines_device_draws_vs_oracle(algo):
     """SgdEngine / SarahEngine on DEVICE-drawn minibatches (a window of steps per draw launch) against the oracle loops fed the

@@ -227,7 +227,7 @@ def _smooth_images(n, count, seed):
 
 def test_full_size_batches_items_do_not_depend_on_the_batch():
     """The benchmarked batch sizes themselves (config 2: B = 1024 through `k_svrg_outer`; config 3: B = 120 through the streaming
-    kernels + DnCNN): a reconstruction never sees its neighbours, and device draws are keyed by (seed, step, problem), so the first
+    kernels + DnCNN; config 4: B = 64 Deblur + NLM + pnp_saga): a reconstruction never sees its neighbours, and device draws are keyed by (seed, step, problem), so the first
     items of the full-size batch must equal, BIT FOR BIT, the same items run in a small batch -- iterate and PSNR log."""
     from pnp_svrg_amd.engine import CsmriBatch, SvrgEngine, TVProx, DnCNNProx
     wts = dict(golden('dncnn_noise15.npz'))
@@ -249,6 +249,23 @@ def test_full_size_batches_items_do_not_depend_on_the_batch():
         assert np.array_equal(out[0][1], out[1][1]), B_full
         del big, small, out
         torch.cuda.empty_cache()
+    # config 4: B = 64 Deblur problems, pnp_saga + NLM on device draws
+    from pnp_svrg_amd.engine import DeblurBatch, NLMProx, make_engine
+    out = []
+    big = DeblurBatch.synthetic(64, 256, 256, 'Minimal', 20.0, seed=100)
+    Bk = np.zeros((256, 256))
+    Bk[0, 0] = Bk[128, 128] = Bk[128, 85] = Bk[128, 64] = 0.25                 # the "Minimal" kernel of DeblurBatch.synthetic (DeblurSR.py:80-89)
+    small = DeblurBatch(big.xrec[:4].double().cpu().numpy(), Bk.ravel() / 65536, big.Y[:4].double().cpu().numpy(),
+                        big.xinit[:4].double().cpu().numpy().reshape(4, -1))
+    for batch in (big, small):
+        eng = make_engine(batch, NLMProx(), 5e6, 1, 3000, algorithm='saga', hist_size=50, seed=1)
+        for _ in range(3):
+            eng.step()
+        out.append((batch.xrec[:4].clone(), eng.z[:4].clone(), eng.psnr_trace()[:, :4].copy()))
+        del eng
+    del big, small
+    torch.cuda.empty_cache()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
 @pytest.mark.parametrize('algo', ['sgd', 'sarah'])

@@ -1,4 +1,4 @@
-"""Forward-pass time of the DnCNN plan at B images, conv mode argv[2] (PNP_DNCNN_SLAB in the environment for mode 6)."""
+"""Forward-pass time of the DnCNN plan at B images, conv mode argv[2]; PNP_HIP_LIB selects an A/B build (tools/ab_tree.sh)."""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -15,4 +15,4 @@ e0.record()
 for _ in range(5): plan.forward(x, out)
 e1.record(); torch.cuda.synchronize()
 ref = ops.DncnnPlan(Wr, 256, 256, B, winograd=5).forward(x)
-print(f'mode {mode} B={B} slab={os.environ.get("PNP_DNCNN_SLAB", "default")}: {e0.elapsed_time(e1) / 5:.3f} ms per forward pass; max |out - mode 5| {float((out - ref).abs().max()):.2e}', flush=True)
+print(f'mode {mode} B={B}: {e0.elapsed_time(e1) / 5:.3f} ms per forward pass; max |out - mode 5| {float((out - ref).abs().max()):.2e}', flush=True)

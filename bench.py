@@ -540,6 +540,8 @@ def main():
                 secondary['dncnn-bf16x3'] = {'metric': metric_name('dncnn'), 'value': round(120 * 10 / dt6, 2), 'unit': 'inner-iters/s',
                                              'steps': 10, 'ms_per_step': round(dt6 / 10 * 1e3, 4), 'dtype': 'bf16x3 (three-way exact split of fp32, fp32 accumulation)',
                                              'config': {'workload': workload_desc('dncnn', wdesc) + ', conv mode 6 (bf16x3-winograd44)', 'batch_per_gpu': 120},
+                                             'note': 'opt-in kernel, fp32-class accuracy (tests: test_bf16x3_conv_mode); currently SLOWER than the exact-fp32 '
+                                                     'default that `value` is measured on -- DESIGN 3.1',
                                              'roofline': w6.roofline(dt6 / 10),
                                              'psnr_db': {'initial_mean': float(np.mean(w6.batch.psnr_init())),
                                                          'after_timed_steps_mean': float(np.mean(tr6[-1]))}}
